@@ -1,0 +1,147 @@
+/*
+ * include/jpeg_gpu.h -- C ABI of the MI355X decode backend (libjpegamd.so).
+ *
+ * This is the boundary SURVEY.md section 8(b) defines: plain pointers and sizes, int status
+ * returns, no C++ types, no exit() inside.  jpeg_read_image() / image_ycbcr_to_rgb() of
+ * include/jpeg.h / include/image.h are a batch of one routed through these entry points; the
+ * batched calls are the throughput product.  Each declaration cites the reference code it
+ * replaces (paths relative to /root/reference/).
+ */
+#ifndef JPEG_GPU_H
+#define JPEG_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-image descriptor: everything jpeg_read_image gets from jpeg_info + scan_info + fp
+ *      (src/jpeg.c:63-88), as flat data -------------------------------------------------- */
+
+typedef struct {
+    uint8_t counts[16];   /* codes of length 1..16: the DHT payload src/hufftree.c:43-62 parses */
+    uint8_t symbols[256]; /* symbols in code order */
+} jdgpu_huff_spec;
+
+typedef struct {
+    const uint8_t *scan;  /* entropy-coded bytes, byte-stuffed, from the byte after SOS to EOF:
+                             what src/bitstream.c:7-18 pulls through getc */
+    size_t   scan_len;
+    uint16_t width, height;          /* src/jpeg.h:15-16 */
+    uint8_t  ncomp;                  /* scan_info.componentCount, 1..3 */
+    struct {
+        uint8_t id;                  /* component id; output channel = id-1 (src/decoding.c:107) */
+        uint8_t H, V, Tq;            /* src/jpeg.h:8-12 */
+        uint8_t Td, Ta;              /* src/jpeg.h:21-25 */
+    } comp[4];                       /* scan order (src/jpeg.c:76) */
+    uint8_t  quant[4][64];           /* zigzag order, src/jpeg.h:13 */
+    jdgpu_huff_spec huff[2][4];      /* [class][id], src/jpeg.h:14 */
+    uint8_t  huff_defined[2][4];
+    uint16_t restart_interval;       /* MCUs; 0 = none.  The reference ignores DRI (src/jpeg.c:50) */
+} jdgpu_image_desc;
+
+/* ---- status codes ---------------------------------------------------------------------- */
+
+enum {
+    JDGPU_OK = 0,
+    JDGPU_ERR_HEADER = -1,       /* jpeg_read_info's -1 (src/jpeg.c:26-54, src/parsing.c) */
+    JDGPU_ERR_NO_DEVICE = -10,   /* no usable HIP device: the product has no CPU fallback */
+    JDGPU_ERR_HIP = -11,         /* a HIP runtime call failed (jdgpu_last_error() has the text) */
+    JDGPU_ERR_ARG = -12,
+    JDGPU_ERR_NOMEM = -13,
+    JDGPU_ERR_UNSUPPORTED = -14, /* sampling factors / component ids outside SURVEY 8(c) contract */
+    JDGPU_ERR_NOT_CONVERGED = -15
+};
+
+/* per-image status bits written by the kernels (jdgpu_batch_status) */
+enum {
+    JDGPU_IMG_EOF = 1,        /* "Reached end of file."                    src/bitstream.c:17 */
+    JDGPU_IMG_NOSYMBOL = 2,   /* "Could not find next symbol in huffnode." src/hufftree.c:69,72 */
+    JDGPU_IMG_UNSUPPORTED = 4,
+    JDGPU_IMG_UNSYNCED = 8    /* internal: segment chain not yet consistent (retried by decode) */
+};
+
+/* flags for jdgpu_batch_create */
+enum {
+    JDGPU_OUT_RGB = 0,        /* fused YCbCr->RGB store: jpeg_read_image + image_ycbcr_to_rgb */
+    JDGPU_OUT_YCBCR = 1,      /* what jpeg_read_image alone leaves in the buffer */
+    JDGPU_PROFILE = 2,        /* record HIP events around every stage of each decode */
+    JDGPU_HOST_PREP = 4       /* debug: unstuff/split the scan on the host instead of on the GPU */
+};
+
+/* stages reported by jdgpu_batch_stage_ms */
+enum {
+    JDGPU_STAGE_UNSTUFF = 0,  /* replaces src/bitstream.c:7-18 */
+    JDGPU_STAGE_SYNC = 1,     /* speculative decode + stitching (no counterpart: src/jpeg.c:74-87 is serial) */
+    JDGPU_STAGE_SCAN = 2,     /* block offsets + DC prediction: src/jpeg.c:73, src/decoding.c:44 */
+    JDGPU_STAGE_WRITE = 3,    /* coefficient write: src/decoding.c:40-66 */
+    JDGPU_STAGE_PIXEL = 4,    /* src/decoding.c:46,65,68-110 + src/image.c:39-51 */
+    JDGPU_STAGE_TOTAL = 5,
+    JDGPU_NSTAGES = 6
+};
+
+/* ---- device ---------------------------------------------------------------------------- */
+
+int         jdgpu_device_count(void);
+int         jdgpu_init(int device);          /* bind the calling process to a device; idempotent */
+const char *jdgpu_last_error(void);          /* thread-local text of the last failure */
+
+/* ---- host-side header parsing on a whole file in memory ---------------------------------
+ * jpeg_read_info (src/jpeg.c:23-58) over a buffer, flattened into a descriptor whose `scan`
+ * points into `file`.  0 or JDGPU_ERR_HEADER / JDGPU_ERR_UNSUPPORTED. */
+int jdgpu_parse_file(const uint8_t *file, size_t len, jdgpu_image_desc *desc);
+
+/* ---- batched decode: replaces jpeg_read_image (src/jpeg.c:63-88) and, with JDGPU_OUT_RGB,
+ *      image_ycbcr_to_rgb (src/image.c:39-51), for n independent images ---------------------- */
+
+typedef struct jdgpu_batch jdgpu_batch;
+
+/* Flattens Huffman tables to lookup tables (replaces the tree walk of src/hufftree.c:64-78),
+ * uploads scan bytes + tables into HBM and allocates coefficient and pixel buffers.  The
+ * descriptors and their scan pointers may be released after this returns. */
+int  jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out);
+/* Enqueue the whole decode (unstuff, sync, scan, write, pixel kernels) on the batch's stream.
+ * Inputs are already resident in HBM; may be called repeatedly. */
+int  jdgpu_batch_decode(jdgpu_batch *b);
+/* Wait for the stream; returns JDGPU_OK or the first failure (per-image detail: _status). */
+int  jdgpu_batch_sync(jdgpu_batch *b);
+void jdgpu_batch_destroy(jdgpu_batch *b);
+
+size_t   jdgpu_batch_size(const jdgpu_batch *b);
+uint32_t jdgpu_batch_status(const jdgpu_batch *b, size_t i);        /* JDGPU_IMG_* bits */
+uint64_t jdgpu_batch_total_pixels(const jdgpu_batch *b);            /* sum of width*height */
+uint64_t jdgpu_batch_total_blocks(const jdgpu_batch *b);            /* 8x8 data units */
+uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b);
+size_t   jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i);
+/* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14) */
+int      jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst);
+void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);       /* device pointer, same layout */
+/* Quantised coefficients, [nblocks][64] int16 in ZIGZAG order, DC un-differenced, decode order
+ * (the values src/decoding.c:44,65 computes before the multiply by the quantisation table). */
+int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
+/* HIP-event milliseconds per stage of the most recent decode (needs JDGPU_PROFILE). */
+int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
+/* number of extra stitching rounds the last decode needed (0 in the common case) */
+int      jdgpu_batch_retries(const jdgpu_batch *b);
+
+/* ---- host-side test hooks: the flattened-table lookup and the unstuff stage as plain C, so the
+ *      CPU test-suite can check them against the tree walk (src/hufftree.c:64-78) and the byte
+ *      reader (src/bitstream.c:7-18) without a GPU.  Not used by any decode call. ------------ */
+/* decode the code at the top of the 16-bit window v16: 0 ok, -1 no such code, -2 bad table */
+int  jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, unsigned *len,
+                           unsigned *run, unsigned *size);
+/* returns the number of 128-byte segments written (each restart interval padded with 0xFF to a
+ * whole segment), -1 if the buffers are too small.  seg_info[i]: bit 31 = first segment of an
+ * interval, low bits = valid bits in the segment. */
+long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
+                        uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap);
+
+/* ---- image.h on the device: src/image.c:39-51 over a host buffer (H2D, kernel, D2H) ------ */
+int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

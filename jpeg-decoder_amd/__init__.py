@@ -1,0 +1,239 @@
+"""jpeg-decoder_amd: MI355X-native baseline-DCT JPEG decode behind the C API of cefqrn/jpeg-decoder.
+
+This Python layer is plumbing over the C ABI (include/jpeg_gpu.h, libjpegamd.so): it loads the
+in-tree shared library with ctypes and mirrors the reference's call sequence
+(jpeg_read_info -> jpeg_read_image -> image_ycbcr_to_rgb, src/test.c:23-36) for batches.
+There is no CPU decode path: without the HIP library or a GPU every decode call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import synth  # noqa: F401  (workload generator, re-exported)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpegamd.so")
+
+# status / flag values of include/jpeg_gpu.h
+OK = 0
+ERR_HEADER = -1
+ERR_NO_DEVICE = -10
+IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
+OUT_RGB, OUT_YCBCR, PROFILE, HOST_PREP = 0, 1, 2, 4
+STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
+
+EXPORTS = [
+    "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_parse_file",
+    "jdgpu_batch_create", "jdgpu_batch_decode", "jdgpu_batch_sync", "jdgpu_batch_destroy",
+    "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
+    "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
+    "jdgpu_batch_read_pixels", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_ycbcr_to_rgb",
+    "jdgpu_host_lut_lookup", "jdgpu_host_unstuff",
+    # include/jpeg.h, include/image.h
+    "jpeg_read_info", "jpeg_read_image", "jpeg_free",
+    "image_print", "image_ycbcr_to_rgb", "image_rgb_to_ycbcr",
+]
+
+
+class HuffSpec(C.Structure):
+    _fields_ = [("counts", C.c_uint8 * 16), ("symbols", C.c_uint8 * 256)]
+
+
+class _Comp(C.Structure):
+    _fields_ = [("id", C.c_uint8), ("H", C.c_uint8), ("V", C.c_uint8), ("Tq", C.c_uint8),
+                ("Td", C.c_uint8), ("Ta", C.c_uint8)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("scan", C.c_void_p), ("scan_len", C.c_size_t),
+                ("width", C.c_uint16), ("height", C.c_uint16), ("ncomp", C.c_uint8),
+                ("comp", _Comp * 4), ("quant", (C.c_uint8 * 64) * 4),
+                ("huff", (HuffSpec * 4) * 2), ("huff_defined", (C.c_uint8 * 4) * 2),
+                ("restart_interval", C.c_uint16)]
+
+
+class JpegError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libjpegamd.so (built in-tree by `make -C jpeg-decoder_amd`); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JpegError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                        "(make -C jpeg-decoder_amd); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
+    L.jdgpu_last_error.restype = C.c_char_p
+    L.jdgpu_parse_file.argtypes = [vp, sz, C.POINTER(ImageDesc)]
+    L.jdgpu_batch_create.argtypes = [C.POINTER(ImageDesc), sz, C.c_uint, C.POINTER(vp)]
+    for f in ("jdgpu_batch_decode", "jdgpu_batch_sync"):
+        getattr(L, f).argtypes = [vp]
+    L.jdgpu_batch_destroy.argtypes = [vp]
+    L.jdgpu_batch_destroy.restype = None
+    L.jdgpu_batch_size.argtypes = [vp]
+    L.jdgpu_batch_size.restype = sz
+    L.jdgpu_batch_status.argtypes = [vp, sz]
+    L.jdgpu_batch_status.restype = C.c_uint32
+    for f in ("jdgpu_batch_total_pixels", "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = C.c_uint64
+    L.jdgpu_batch_image_blocks.argtypes = [vp, sz]
+    L.jdgpu_batch_image_blocks.restype = sz
+    L.jdgpu_batch_read_pixels.argtypes = [vp, sz, vp]
+    L.jdgpu_batch_device_pixels.argtypes = [vp, sz]
+    L.jdgpu_batch_device_pixels.restype = vp
+    L.jdgpu_batch_read_coefficients.argtypes = [vp, sz, vp]
+    L.jdgpu_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.jdgpu_batch_retries.argtypes = [vp]
+    L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
+    L.jdgpu_host_lut_lookup.argtypes = [C.POINTER(HuffSpec), C.c_int, C.c_uint, C.POINTER(C.c_uint),
+                                        C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
+    L.jdgpu_host_unstuff.restype = C.c_long
+    _lib = L
+    return L
+
+
+def _err(L, what, rc):
+    return JpegError(f"{what} failed ({rc}): {L.jdgpu_last_error().decode(errors='replace')}")
+
+
+def parse(data):
+    """jpeg_read_info over bytes -> ImageDesc (its scan pointer aliases a kept numpy copy)."""
+    L = lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    d = ImageDesc()
+    rc = L.jdgpu_parse_file(buf.ctypes.data, buf.size, C.byref(d))
+    if rc:
+        raise JpegError(f"header rejected ({rc})")
+    d._keep = buf
+    return d
+
+
+class Batch:
+    """A decode batch resident on one GPU (jdgpu_batch)."""
+
+    def __init__(self, descs, flags=OUT_RGB):
+        L = self._L = lib()
+        self.descs = list(descs)
+        arr = (ImageDesc * max(1, len(self.descs)))(*self.descs)
+        h = C.c_void_p()
+        rc = L.jdgpu_batch_create(arr, len(self.descs), flags, C.byref(h))
+        if rc:
+            raise _err(L, "jdgpu_batch_create", rc)
+        self._h = h
+        self.flags = flags
+        self.n = len(self.descs)
+        self.dims = [(d.width, d.height) for d in self.descs]
+
+    def decode(self, sync=True):
+        rc = self._L.jdgpu_batch_decode(self._h)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_decode", rc)
+        if sync:
+            self.sync()
+        return self
+
+    def sync(self):
+        rc = self._L.jdgpu_batch_sync(self._h)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_sync", rc)
+
+    def status(self, i):
+        return int(self._L.jdgpu_batch_status(self._h, i))
+
+    def pixels(self, i):
+        w, h = self.dims[i]
+        out = np.empty((h, w, 3), np.uint8)
+        rc = self._L.jdgpu_batch_read_pixels(self._h, i, out.ctypes.data)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_read_pixels", rc)
+        return out
+
+    rgb = pixels
+
+    def qcoef(self, i):
+        """quantised coefficients [nblocks, 64] int16, zigzag order, decode order"""
+        nb = self._L.jdgpu_batch_image_blocks(self._h, i)
+        out = np.empty((nb, 64), np.int16)
+        rc = self._L.jdgpu_batch_read_coefficients(self._h, i, out.ctypes.data)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_read_coefficients", rc)
+        return out
+
+    def stage_ms(self):
+        ms = (C.c_float * len(STAGES))()
+        rc = self._L.jdgpu_batch_stage_ms(self._h, ms)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_stage_ms", rc)
+        return dict(zip(STAGES, [float(x) for x in ms]))
+
+    @property
+    def total_pixels(self):
+        return int(self._L.jdgpu_batch_total_pixels(self._h))
+
+    @property
+    def total_blocks(self):
+        return int(self._L.jdgpu_batch_total_blocks(self._h))
+
+    @property
+    def total_scan_bytes(self):
+        return int(self._L.jdgpu_batch_total_scan_bytes(self._h))
+
+    @property
+    def retries(self):
+        return int(self._L.jdgpu_batch_retries(self._h))
+
+    def device_pixels(self, i):
+        return int(self._L.jdgpu_batch_device_pixels(self._h, i) or 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jdgpu_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Decoder:
+    """Binds the process to one MI355X and decodes lists of JPEG byte strings."""
+
+    def __init__(self, device=0):
+        L = self._L = lib()
+        rc = L.jdgpu_init(device)
+        if rc:
+            raise _err(L, "jdgpu_init", rc)
+        self.device = device
+
+    def batch(self, files, flags=OUT_RGB):
+        return Batch([parse(f) for f in files], flags)
+
+    def decode(self, files, flags=OUT_RGB):
+        return self.batch(files, flags).decode()
+
+
+def ycbcr_to_rgb(img):
+    """image_ycbcr_to_rgb (src/image.c:39-51) on the GPU over an (h, w, 3) uint8 array."""
+    L = lib()
+    out = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    h, w = out.shape[:2]
+    rc = L.jdgpu_ycbcr_to_rgb(out.ctypes.data, w, h)
+    if rc:
+        raise _err(L, "jdgpu_ycbcr_to_rgb", rc)
+    return out
+
+
+def device_count():
+    return int(lib().jdgpu_device_count())

@@ -1,0 +1,965 @@
+/*
+ * jdgpu.hip -- MI355X (gfx950, wave64) baseline-JPEG decode kernels and the C ABI of
+ * include/jpeg_gpu.h.  Written for CDNA4 only: no CUDA paths, no portability layer.
+ *
+ * Pipeline of one jdgpu_batch_decode (all on one HIP stream, inputs resident in HBM):
+ *
+ *   unstuff   k_unstuff_*      stuffed scan bytes -> clean stream, one restart interval after
+ *                              the other, each padded to whole 1024-bit segments
+ *                              (replaces src/bitstream.c:7-18 of the reference)
+ *   sync      k_huff_sync      one lane per segment: decode speculatively from the segment
+ *                              start, then re-decode from the predecessor's exit state until
+ *                              the states of a 256-segment work-group stop changing
+ *                              (self-synchronisation); k_huff_resync stitches work-groups
+ *   scan      k_seg_scan       segmented prefix sums: first data-unit index and DC predictors
+ *                              at every segment start (src/jpeg.c:73, src/decoding.c:44)
+ *   write     k_huff_write     final decode from the now-known start states; writes quantised
+ *                              int16 coefficients (src/decoding.c:40-66)
+ *   pixel     k_pixel          dequantise, separable fp64 IDCT through LDS, level shift, clamp,
+ *                              replicate chroma, YCbCr->RGB, coalesced 12-byte stores
+ *                              (src/decoding.c:46,65,68-110, src/image.c:39-51)
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "jdgpu_internal.h"
+
+/* ============================================================================================
+ * small helpers
+ * ========================================================================================== */
+
+static thread_local char g_err[512] = "";
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call,            \
+                     hipGetErrorString(e_));                                                      \
+            return JDGPU_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+#define SEG_STRIDE (JD_SEG_WORDS + 1u) /* LDS words per staged segment: +1 breaks bank aliasing */
+#define SEG_MASK 0x7FFu
+
+/* ============================================================================================
+ * Huffman: per-lane sequential decoder over one 1024-bit segment
+ * ========================================================================================== */
+
+struct SegTables {
+    const jd_lut *lut;      /* LDS copy of the image's JD_LUT_SLOTS tables */
+    const uint16_t *blk;    /* LDS: per data unit of the MCU: dc slot | ac slot << 4 | comp << 8 */
+    uint32_t bpm;
+};
+
+/* word w (may run a little past 32) of the lane's staged segment */
+struct LdsWords {
+    const uint32_t *base; /* &s_words[lane * SEG_STRIDE] */
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const {
+        return __builtin_bswap32(base[w + (w >> 5)]);
+    }
+};
+/* the same words straight from the clean stream in global memory */
+struct GlobalWords {
+    const uint32_t *base;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const {
+        return __builtin_bswap32(base[w]);
+    }
+};
+
+typedef jd_sym SymInfo;
+#define lookup jd_lut_lookup
+
+/* JPEG EXTEND (src/decoding.c:31-33), size 0 -> 0 */
+__device__ __forceinline__ int extend(uint32_t bits, uint32_t size) {
+    return (size == 0) ? 0 : ((bits >> (size - 1)) ? (int)bits : (int)bits - (int)(1u << size) + 1);
+}
+
+struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
+
+/*
+ * Light decode (no coefficient output): from packed start state `in` run to the end of the
+ * segment's valid bits; report the exit state, the number of data units COMPLETED and the sum
+ * of DC differences seen per component.
+ */
+template <class Words>
+__device__ __forceinline__ LightResult decode_light(const Words &W, const SegTables &T, uint32_t in,
+                                                    uint32_t valid) {
+    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
+    uint32_t bad = 0;
+    int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    uint32_t wi = p >> 5;
+    uint64_t buf = ((uint64_t)W(wi) << 32) | W(wi + 1);
+    buf <<= (p & 31u);
+    uint32_t cnt = 64u - (p & 31u);
+    wi += 2;
+    uint32_t tb = T.blk[b];
+    while (p < valid) {
+        uint32_t top = (uint32_t)(buf >> 32);
+        bool isdc = (k == 0);
+        const jd_lut *t = T.lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
+        SymInfo s = lookup(t, top >> 16);
+        bad |= s.bad;
+        uint32_t tot = s.len + s.size;
+        if (isdc) {
+            uint32_t mag = s.size ? ((top << s.len) >> (32u - s.size)) : 0u;
+            int d = extend(mag, s.size);
+            uint32_t c = tb >> 8;
+            dc0 += (c == 0) ? d : 0; dc1 += (c == 1) ? d : 0; dc2 += (c == 2) ? d : 0;
+            k = 1;
+        } else {
+            /* src/decoding.c:53-63: i += run; size 0: run 15 -> skip 16, else end of block */
+            k = (s.size == 0 && s.run != 15u) ? 64u : k + s.run + 1u;
+        }
+        p += tot;
+        buf <<= tot;
+        cnt -= tot;
+        if (cnt <= 32u) { buf |= (uint64_t)W(wi) << (32u - cnt); cnt += 32u; ++wi; }
+        if (k >= 64u) {
+            k = 0; ++n;
+            b = (b + 1 == T.bpm) ? 0 : b + 1;
+            tb = T.blk[b];
+        }
+    }
+    LightResult r;
+    uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
+    r.exit_state = JD_ST_PACK(ovs, k, b) | (bad ? JD_ST_BAD : 0u);
+    r.n = n; r.dc0 = dc0; r.dc1 = dc1; r.dc2 = dc2;
+    return r;
+}
+
+/* cooperative staging of JD_WG_SEGS+1 segments of the clean stream into padded LDS rows */
+__device__ __forceinline__ void stage_segments(uint32_t *s_words, const uint8_t *clean_img,
+                                               uint32_t seg0, uint32_t n_segs) {
+    const uint32_t nchunk = (JD_WG_SEGS + 1) * (JD_SEG_BYTES / 16);
+    for (uint32_t c = threadIdx.x; c < nchunk; c += blockDim.x) {
+        uint32_t s = c >> 3, q = c & 7u;
+        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (seg0 + s < n_segs) v = *reinterpret_cast<const uint4 *>(clean_img + (size_t)(seg0 + s) * JD_SEG_BYTES + q * 16);
+        uint32_t *d = s_words + s * SEG_STRIDE + q * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void stage_tables(jd_lut *s_lut, uint16_t *s_blk, const jd_lut *g_lut, const jd_image &im) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
+    for (uint32_t i = threadIdx.x; i < JD_LUT_SLOTS * sizeof(jd_lut) / 16; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < JD_MAX_BPM)
+        s_blk[threadIdx.x] = (uint16_t)(im.blk_dc[threadIdx.x] | (im.blk_ac[threadIdx.x] << 4) | (im.blk_comp[threadIdx.x] << 8));
+}
+
+/*
+ * k_huff_sync: speculative decode + intra-work-group stitching.
+ * st_in/st_exit/cnt: per segment start state used, exit state reached, counts.
+ * wg_exit[w]: exit state of the work-group's last segment (input of work-group w+1).
+ */
+__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__restrict__ imgs,
+                                                          const jd_lut *__restrict__ luts,
+                                                          const uint8_t *__restrict__ clean,
+                                                          const uint32_t *__restrict__ seg_info,
+                                                          const jd_huff_wg *__restrict__ wgs,
+                                                          uint32_t *__restrict__ st_in,
+                                                          uint32_t *__restrict__ st_exit,
+                                                          int4 *__restrict__ cnt,
+                                                          uint32_t *__restrict__ wg_exit) {
+    __shared__ uint32_t s_words[(JD_WG_SEGS + 1) * SEG_STRIDE];
+    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ uint16_t s_blk[16];
+    __shared__ uint32_t s_exit[JD_WG_SEGS];
+
+    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    const uint32_t n_segs = im.n_segs;
+    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
+    if (wg.seg0 >= n_segs) {
+        if (lane == 0) wg_exit[blockIdx.x] = 0;
+        return;
+    }
+    stage_segments(s_words, clean + im.clean_off, wg.seg0, n_segs);
+    stage_tables(s_lut, s_blk, luts + im.lut_off, im);
+    __syncthreads();
+
+    const bool active = seg < n_segs;
+    const uint32_t si = active ? seg_info[im.seg_off + seg] : JD_SEG_FIRST;
+    const bool first = (si & JD_SEG_FIRST) != 0;
+    const uint32_t valid = si & SEG_MASK;
+    SegTables T{s_lut, s_blk, im.bpm};
+    LdsWords W{s_words + lane * SEG_STRIDE};
+
+    uint32_t in = 0; /* guess == true start state of an interval: bit 0, expecting DC, unit 0 */
+    LightResult r = decode_light(W, T, in, active ? valid : 0u);
+    for (uint32_t round = 0; round < JD_WG_SEGS; ++round) {
+        s_exit[lane] = r.exit_state & ~JD_ST_BAD;
+        __syncthreads();
+        uint32_t nin = (first || lane == 0) ? in : s_exit[lane - 1];
+        bool ch = active && nin != in;
+        if (ch) { in = nin; r = decode_light(W, T, in, valid); }
+        if (!__syncthreads_or(ch)) break;
+    }
+    if (active) {
+        st_in[im.seg_off + seg] = in;
+        st_exit[im.seg_off + seg] = r.exit_state;
+        cnt[im.seg_off + seg] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+    }
+    uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
+    if (lane == last) wg_exit[blockIdx.x] = r.exit_state & ~JD_ST_BAD;
+}
+
+/*
+ * k_huff_resync: stitch work-groups.  Lane 0 of every work-group takes the exit state of the
+ * previous work-group's last segment; lanes whose input changes re-decode (straight from
+ * global memory: only a lane or two per work-group does any work) until the change dies out.
+ * Reads wg_exit_in (previous round), writes wg_exit_out; *changed counts work-groups whose
+ * own last exit state moved (then another round is needed).
+ */
+__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_resync(const jd_image *__restrict__ imgs,
+                                                            const jd_lut *__restrict__ luts,
+                                                            const uint8_t *__restrict__ clean,
+                                                            const uint32_t *__restrict__ seg_info,
+                                                            const jd_huff_wg *__restrict__ wgs,
+                                                            uint32_t *__restrict__ st_in,
+                                                            uint32_t *__restrict__ st_exit,
+                                                            int4 *__restrict__ cnt,
+                                                            const uint32_t *__restrict__ wg_exit_in,
+                                                            uint32_t *__restrict__ wg_exit_out,
+                                                            uint32_t *__restrict__ changed) {
+    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ uint16_t s_blk[16];
+    __shared__ uint32_t s_exit[JD_WG_SEGS];
+
+    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    const uint32_t n_segs = im.n_segs;
+    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
+    if (wg.seg0 >= n_segs) {
+        if (lane == 0) wg_exit_out[blockIdx.x] = 0;
+        return;
+    }
+    const bool active = seg < n_segs;
+    const uint32_t si = active ? seg_info[im.seg_off + seg] : JD_SEG_FIRST;
+    const bool first = (si & JD_SEG_FIRST) != 0;
+    const uint32_t valid = si & SEG_MASK;
+    uint32_t in = active ? st_in[im.seg_off + seg] : 0u;
+    uint32_t ex = active ? st_exit[im.seg_off + seg] : 0u;
+    const uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
+
+    /* work-group 0 of an image starts an interval; others chain to their predecessor */
+    uint32_t nin0 = (first || wg.seg0 == 0) ? in : wg_exit_in[blockIdx.x - 1];
+    bool ch = active && lane == 0 && nin0 != in;
+    if (!__syncthreads_or(ch)) {
+        if (lane == last) wg_exit_out[blockIdx.x] = ex & ~JD_ST_BAD;
+        return;
+    }
+    stage_tables(s_lut, s_blk, luts + im.lut_off, im);
+    __syncthreads();
+    SegTables T{s_lut, s_blk, im.bpm};
+    GlobalWords W{reinterpret_cast<const uint32_t *>(clean + im.clean_off + (size_t)seg * JD_SEG_BYTES)};
+    LightResult r; r.exit_state = ex; r.n = 0; r.dc0 = r.dc1 = r.dc2 = 0;
+    bool dirty = false;
+    uint32_t nin = nin0;
+    for (uint32_t round = 0; round <= JD_WG_SEGS; ++round) {
+        if (ch) { in = nin; r = decode_light(W, T, in, valid); dirty = true; }
+        s_exit[lane] = r.exit_state & ~JD_ST_BAD;
+        __syncthreads();
+        nin = (first || lane == 0) ? in : s_exit[lane - 1];
+        ch = active && nin != in;
+        if (!__syncthreads_or(ch)) break;
+    }
+    if (dirty) {
+        st_in[im.seg_off + seg] = in;
+        st_exit[im.seg_off + seg] = r.exit_state;
+        cnt[im.seg_off + seg] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+    }
+    if (lane == last) {
+        wg_exit_out[blockIdx.x] = r.exit_state & ~JD_ST_BAD;
+        if (dirty && ((r.exit_state ^ ex) & ~JD_ST_BAD)) atomicAdd(changed, 1u);
+    }
+}
+
+/* ============================================================================================
+ * scan: first data unit and DC predictors at every segment start
+ * ========================================================================================== */
+
+struct ScanVal { int n, d0, d1, d2; uint32_t f; }; /* f: number of interval starts covered */
+
+__device__ __forceinline__ ScanVal scan_combine(const ScanVal &a, const ScanVal &b) {
+    /* b follows a; an interval start inside b resets the running sums */
+    ScanVal r;
+    if (b.f) { r = b; r.f = a.f + b.f; }
+    else { r.n = a.n + b.n; r.d0 = a.d0 + b.d0; r.d1 = a.d1 + b.d1; r.d2 = a.d2 + b.d2; r.f = a.f; }
+    return r;
+}
+
+__device__ __forceinline__ ScanVal shfl_up_val(const ScanVal &v, int d) {
+    ScanVal o;
+    o.n = __shfl_up(v.n, d); o.d0 = __shfl_up(v.d0, d); o.d1 = __shfl_up(v.d1, d);
+    o.d2 = __shfl_up(v.d2, d); o.f = __shfl_up(v.f, d);
+    return o;
+}
+
+/* one work-group per image; inclusive segmented scan in chunks of 256 with a running carry */
+__global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ imgs,
+                                                  const uint32_t *__restrict__ seg_info,
+                                                  const int4 *__restrict__ cnt,
+                                                  int2 *__restrict__ start_blk,
+                                                  int4 *__restrict__ start_dc) {
+    __shared__ ScanVal s_wave[4];
+    __shared__ ScanVal s_carry;
+    const jd_image &im = imgs[blockIdx.x];
+    const uint32_t n_segs = im.n_segs, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_carry.n = s_carry.d0 = s_carry.d1 = s_carry.d2 = 0; s_carry.f = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_segs; base += 256) {
+        uint32_t seg = base + threadIdx.x;
+        bool act = seg < n_segs;
+        ScanVal v; v.n = v.d0 = v.d1 = v.d2 = 0; v.f = 0;
+        bool first = false;
+        if (act) {
+            int4 c = cnt[im.seg_off + seg];
+            first = (seg_info[im.seg_off + seg] & JD_SEG_FIRST) != 0;
+            v.n = c.x; v.d0 = c.y; v.d1 = c.z; v.d2 = c.w; v.f = first ? 1u : 0u;
+        }
+        ScanVal own = v;
+        /* wave-level inclusive scan (Hillis-Steele over 64 lanes) */
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            ScanVal o = shfl_up_val(v, d);
+            if ((int)lane >= d) v = scan_combine(o, v);
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        ScanVal pre = s_carry;
+        for (uint32_t w = 0; w < wave; ++w) pre = scan_combine(pre, s_wave[w]);
+        ScanVal inc = scan_combine(pre, v); /* inclusive over everything up to this segment */
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = inc;
+        if (act) {
+            /* exclusive value: state before this segment's own contribution */
+            int ivl = (int)inc.f - 1; /* interval index of this segment */
+            int ri = (int)im.ri_blocks;
+            int ibase = ri ? ivl * ri : 0;
+            int limit = ri ? min(ibase + ri, (int)im.n_blocks) : (int)im.n_blocks;
+            int b0, p0, p1, p2;
+            if (first) { b0 = ibase; p0 = p1 = p2 = 0; }
+            else { b0 = ibase + inc.n - own.n; p0 = inc.d0 - own.d0; p1 = inc.d1 - own.d1; p2 = inc.d2 - own.d2; }
+            start_blk[im.seg_off + seg] = make_int2(b0, limit);
+            start_dc[im.seg_off + seg] = make_int4(p0, p1, p2, 0);
+        }
+        __syncthreads();
+    }
+}
+
+/* ============================================================================================
+ * write: final decode, coefficients out
+ * ========================================================================================== */
+
+__constant__ uint8_t c_zz_cm[64];
+
+__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__restrict__ imgs,
+                                                           const jd_lut *__restrict__ luts,
+                                                           const uint8_t *__restrict__ clean,
+                                                           const uint32_t *__restrict__ seg_info,
+                                                           const jd_huff_wg *__restrict__ wgs,
+                                                           const uint32_t *__restrict__ st_in,
+                                                           const uint32_t *__restrict__ st_exit,
+                                                           const int2 *__restrict__ start_blk,
+                                                           const int4 *__restrict__ start_dc,
+                                                           int16_t *__restrict__ coef,
+                                                           uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_words[(JD_WG_SEGS + 1) * SEG_STRIDE];
+    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ uint16_t s_blk[16];
+    __shared__ uint8_t s_cm[64];
+
+    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    const uint32_t n_segs = im.n_segs;
+    if (wg.seg0 >= n_segs) return;
+    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
+    stage_segments(s_words, clean + im.clean_off, wg.seg0, n_segs);
+    stage_tables(s_lut, s_blk, luts + im.lut_off, im);
+    if (lane < 64) s_cm[lane] = c_zz_cm[lane];
+    __syncthreads();
+    if (seg >= n_segs) return;
+
+    const uint32_t gs = im.seg_off + seg;
+    const uint32_t si = seg_info[gs];
+    const bool first = (si & JD_SEG_FIRST) != 0;
+    const uint32_t valid = si & SEG_MASK;
+    /* bits this lane may consume: its own segment plus, when that is full and the interval
+     * goes on, the next one (a symbol may straddle the boundary) */
+    uint32_t avail = valid;
+    bool is_last = true; /* last segment of its restart interval */
+    if (seg + 1 < n_segs) {
+        uint32_t sn = seg_info[gs + 1];
+        if (!(sn & JD_SEG_FIRST)) { is_last = false; avail += sn & SEG_MASK; }
+    }
+    const uint32_t in = st_in[gs];
+    uint32_t flags = 0;
+    /* chain check: the state this segment starts from must be the one its predecessor ended in */
+    if (!first && seg > 0 && ((st_exit[gs - 1] ^ in) & ~JD_ST_BAD)) flags |= JDGPU_IMG_UNSYNCED;
+    if (first && in != 0) flags |= JDGPU_IMG_UNSYNCED;
+
+    const int2 sb = start_blk[gs];
+    const int4 sd = start_dc[gs];
+    int B = sb.x;
+    const int limit = sb.y;
+    int pr0 = sd.x, pr1 = sd.y, pr2 = sd.z;
+
+    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
+    LdsWords W{s_words + lane * SEG_STRIDE};
+    uint32_t wi = p >> 5;
+    uint64_t buf = ((uint64_t)W(wi) << 32) | W(wi + 1);
+    buf <<= (p & 31u);
+    uint32_t cnt = 64u - (p & 31u);
+    wi += 2;
+    uint32_t tb = s_blk[b];
+    int16_t *cb = coef + ((size_t)im.blk_off + (size_t)B) * 64;
+
+    while (p < valid && B < limit) {
+        uint32_t top = (uint32_t)(buf >> 32);
+        bool isdc = (k == 0);
+        const jd_lut *t = s_lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
+        SymInfo s = lookup(t, top >> 16);
+        uint32_t tot = s.len + s.size;
+        if (p + tot > avail) { flags |= JDGPU_IMG_EOF; break; }   /* src/bitstream.c:17 */
+        if (s.bad) { flags |= JDGPU_IMG_NOSYMBOL; break; }        /* src/hufftree.c:69,72 */
+        uint32_t mag = s.size ? ((top << s.len) >> (32u - s.size)) : 0u;
+        int val = extend(mag, s.size);
+        if (isdc) {
+            uint32_t c = tb >> 8;
+            int pv;
+            if (c == 0) { pr0 += val; pv = pr0; } else if (c == 1) { pr1 += val; pv = pr1; } else { pr2 += val; pv = pr2; }
+            cb[0] = (int16_t)pv;   /* src/decoding.c:44-46 (quantised: the multiply is in k_pixel) */
+            k = 1;
+        } else {
+            uint32_t kk = k + s.run;
+            if (s.size == 0) {
+                k = (s.run == 15u) ? kk + 1u : 64u;
+            } else {
+                if (kk < 64u) cb[s_cm[kk]] = (int16_t)val;  /* src/decoding.c:65 */
+                k = kk + 1u;
+            }
+        }
+        p += tot;
+        buf <<= tot;
+        cnt -= tot;
+        if (cnt <= 32u) { buf |= (uint64_t)W(wi) << (32u - cnt); cnt += 32u; ++wi; }
+        if (k >= 64u) {
+            k = 0; ++B; cb += 64;
+            b = (b + 1 == im.bpm) ? 0 : b + 1;
+            tb = s_blk[b];
+        }
+    }
+    /* the light pass must have seen exactly this: same exit state when the segment ran to its end */
+    if (!(flags & (JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) && B < limit && !is_last) {
+        uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
+        if ((JD_ST_PACK(ovs, k, b) ^ st_exit[gs]) & ~JD_ST_BAD) flags |= JDGPU_IMG_UNSYNCED;
+    }
+    /* data ended before the interval's data units did */
+    if (!flags && B < limit && is_last) flags |= JDGPU_IMG_EOF;
+    if (flags) atomicOr(&status[wg.img], flags);
+}
+
+/* ============================================================================================
+ * pixel stage
+ * ========================================================================================== */
+
+/* src/decoding.c:20-29: C(u) cos((2x+1) u pi/16) rounded to six decimals */
+#define T0 0.707107
+#define T1 0.980785
+#define T2 0.923880
+#define T3 0.831470
+#define T5 0.555570
+#define T6 0.382683
+#define T7 0.195090
+
+/* 8-point inverse transform with the reference's table, even/odd split:
+ * out[x] = sum_u in[u] * T[u][x];  T[u][7-x] = (-1)^u T[u][x] */
+__device__ __forceinline__ void idct8(const double in[8], double out[8]) {
+    double e0 = in[0] * T0, e4 = in[4] * T0;
+    double a0 = e0 + e4, a1 = e0 - e4;                       /* u = 0, 4 */
+    double b0 = fma(in[2], T2, in[6] * T6);                  /* u = 2, 6 at x = 0 */
+    double b1 = fma(in[2], T6, -(in[6] * T2));               /* at x = 1 */
+    double E0 = a0 + b0, E3 = a0 - b0, E1 = a1 + b1, E2 = a1 - b1;
+    double O0 = fma(in[1], T1, fma(in[3], T3, fma(in[5], T5, in[7] * T7)));
+    double O1 = fma(in[1], T3, fma(in[3], -T7, fma(in[5], -T1, in[7] * -T5)));
+    double O2 = fma(in[1], T5, fma(in[3], -T1, fma(in[5], T7, in[7] * T3)));
+    double O3 = fma(in[1], T7, fma(in[3], -T5, fma(in[5], T3, in[7] * -T1)));
+    out[0] = E0 + O0; out[7] = E0 - O0;
+    out[1] = E1 + O1; out[6] = E1 - O1;
+    out[2] = E2 + O2; out[5] = E2 - O2;
+    out[3] = E3 + O3; out[4] = E3 - O3;
+}
+
+/* src/decoding.c:99: clamp(lround(v) + 128, 0, 255); lround = half away from zero */
+__device__ __forceinline__ uint32_t to_sample(double v) {
+    double r = v + copysign(0.5, v);
+    int i = (int)r + 128; /* conversion truncates toward zero */
+    return (uint32_t)min(max(i, 0), 255);
+}
+
+/*
+ * Exact integer form of the reference colour transform (src/image.c:44-48, doubles, clamp,
+ * truncating store).  For Y in 0..255 and cb, cr in -128..127:
+ *   R = clamp(Y + floor(1.402 cr)), B = clamp(Y + floor(1.772 cb)),
+ *   G = clamp(Y + floor(-(34414 cb + 71414 cr) / 100000))
+ * The real-valued sums are never within 1e-6 of an integer unless they are integers, so the
+ * double evaluation and the exact rational floor agree except where the real value IS an
+ * integer (cb,cr = -100,100 and 100,-100); those are handled below and the whole function is
+ * checked over all 2^24 triples against the oracle (tests/test_gpu_parity.py).
+ */
+struct ChromaTerms { int dr, dg, db; uint32_t exc; };
+__device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
+    int cb = cbv - 128, cr = crv - 128;
+    ChromaTerms t;
+    /* floor(n / 1000) and floor(n / 100000) by multiply-high on a numerator shifted positive:
+     * ceil(2^32/1000) = 4294968 is exact for n < 6e6, ceil(2^48/1e5) = 2814749768 for n < 2^26 */
+    t.dr = (int)__umulhi((uint32_t)(1402 * cr + 256000), 4294968u) - 256;
+    t.db = (int)__umulhi((uint32_t)(1772 * cb + 256000), 4294968u) - 256;
+    uint32_t n = (uint32_t)(25600000 - (34414 * cb + 71414 * cr));
+    t.dg = (int)(((uint64_t)n * 2814749768ull) >> 48) - 256;
+    /* the one place where double rounding in src/image.c:46 shows: Cb = 28, Cr = 228 gives
+     * exactly Y - 37 in real arithmetic, but (Y + 34.414) - 71.414 in doubles lands just below
+     * the integer for Y in 94..165, and the truncating store then yields one less */
+    t.exc = (cbv == 28 && crv == 228) ? 1u : 0u;
+    return t;
+}
+__device__ __forceinline__ int green_fix(const ChromaTerms &t, int Y) {
+    return (int)(t.exc & (uint32_t)((uint32_t)(Y - 94) <= 71u));
+}
+
+__device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+#define PIX_ROW_PAD 8u            /* bytes added to each sample-tile row */
+#define TR_BLK_BYTES (512u + 64u) /* transpose buffer per 8x8 block of doubles */
+
+/*
+ * k_pixel: one work-group per strip of an MCU row (JD_STRIP_PX pixels wide).
+ *   phase 1: 8 lanes per data unit.  Lane u loads column u of the block (coefficients are stored
+ *            column-major: 16 contiguous bytes), dequantises, does the vertical 8-point
+ *            transform, transposes through LDS, does the horizontal transform for row y, rounds
+ *            and writes 8 samples of one row into the component's sample tile in LDS.
+ *   phase 2: 4 pixels per lane: gather Y/Cb/Cr (replicated chroma), colour transform, one
+ *            12-byte store; 64 lanes cover 768 contiguous bytes of an output row.
+ * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces).
+ */
+template <bool OUT_YCBCR>
+__global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs,
+                                               const jd_pix_wg *__restrict__ wgs,
+                                               const int16_t *__restrict__ coef,
+                                               uint8_t *__restrict__ pix) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tr[32 * TR_BLK_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[3][16 * (JD_STRIP_PX + PIX_ROW_PAD)];
+    __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
+
+    const jd_pix_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t maxH = im.maxH, maxV = im.maxV, bpm = im.bpm;
+    const uint32_t strip_mcus = min((uint32_t)(JD_STRIP_PX / (8u * maxH)), im.mcus_x - wg.mcu_col0);
+    const uint32_t nblk = strip_mcus * bpm;
+    s_q[tid >> 6][tid & 63u] = im.quant[tid >> 6][tid & 63u];
+    __syncthreads();
+
+    /* ---- phase 1 ---- */
+    const uint32_t l = tid & 7u, slot = tid >> 3;
+    const size_t mcu0 = (size_t)wg.mcu_row * im.mcus_x + wg.mcu_col0;
+    for (uint32_t j0 = 0; j0 < nblk; j0 += 32) {
+        uint32_t j = j0 + slot;
+        bool act = j < nblk;
+        uint32_t m = 0, b = 0, c = 0;
+        double col[8], t[8];
+        if (act) {
+            m = j / bpm; b = j - m * bpm; c = im.blk_comp[b];
+            const int16_t *src = coef + ((size_t)im.blk_off + (mcu0 + m) * bpm + b) * 64 + l * 8;
+            uint4 raw = *reinterpret_cast<const uint4 *>(src);
+            uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[im.comp_tq[c]][l * 8]);
+            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int lo = (int)(int16_t)(rw[i] & 0xFFFFu), hi = (int)(int16_t)(rw[i] >> 16);
+                col[2 * i] = (double)(lo * (int)(qw[i] & 0xFFFFu));       /* src/decoding.c:46,65 */
+                col[2 * i + 1] = (double)(hi * (int)(qw[i] >> 16));
+            }
+            idct8(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
+            double *tr = reinterpret_cast<double *>(s_tr + slot * TR_BLK_BYTES);
+#pragma unroll
+            for (int y = 0; y < 8; ++y) tr[y * 8 + l] = t[y];
+        }
+        __syncthreads();
+        if (act) {
+            const double *tr = reinterpret_cast<const double *>(s_tr + slot * TR_BLK_BYTES);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + u];
+            idct8(col, t); /* horizontal: row y = l, t[x] */
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                w0 |= to_sample(t[x] * 0.25) << (8 * x);          /* src/decoding.c:83: sum / 4 */
+                w1 |= to_sample(t[x + 4] * 0.25) << (8 * x);
+            }
+            uint32_t row = im.blk_v[b] * 8u + l;
+            uint32_t colpx = (m * im.comp_H[c] + im.blk_h[b]) * 8u;
+            *reinterpret_cast<uint2 *>(&s_tile[c][row * (JD_STRIP_PX + PIX_ROW_PAD) + colpx]) = make_uint2(w0, w1);
+        }
+        __syncthreads();
+    }
+
+    /* ---- phase 2 ---- */
+    const uint32_t W = im.width, H = im.height;
+    const uint32_t x0 = wg.mcu_col0 * 8u * maxH, y0 = wg.mcu_row * 8u * maxV;
+    const uint32_t rows = min(8u * maxV, H - y0);
+    const uint32_t g = tid & 63u, x = x0 + 4u * g;
+    /* per component: horizontal / vertical replication shift (maxH/H in {1,2}: src/jpeg.c:82) */
+    uint32_t hs[3], vs[3], ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
+    }
+    uint8_t *out = pix + im.pix_off;
+    const bool fast = ((W & 3u) == 0);
+    if (x < W && 4u * g < strip_mcus * 8u * maxH) {
+        for (uint32_t r = tid >> 6; r < rows; r += 4) {
+            uint32_t s[3][4]; /* s[channel][pixel] */
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint8_t *tp = &s_tile[c][(r >> vs[c]) * (JD_STRIP_PX + PIX_ROW_PAD)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t v = tp[(4u * g + i) >> hs[c]];
+                    /* channel = component id - 1 (src/decoding.c:107) */
+                    if (ch[c] == 0) s[0][i] = v; else if (ch[c] == 1) s[1][i] = v; else s[2][i] = v;
+                }
+            }
+            uint32_t o[12];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (OUT_YCBCR) { o[3 * i] = s[0][i]; o[3 * i + 1] = s[1][i]; o[3 * i + 2] = s[2][i]; }
+                else {
+                    ChromaTerms ct = chroma_terms((int)s[1][i], (int)s[2][i]);
+                    o[3 * i] = clamp255((int)s[0][i] + ct.dr);
+                    o[3 * i + 1] = clamp255((int)s[0][i] + ct.dg - green_fix(ct, (int)s[0][i]));
+                    o[3 * i + 2] = clamp255((int)s[0][i] + ct.db);
+                }
+            }
+            size_t off = ((size_t)(y0 + r) * W + x) * 3;
+            if (fast) {
+                uint32_t d0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+                uint32_t d1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+                uint32_t d2 = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(out + off);
+                dst[0] = d0; dst[1] = d1; dst[2] = d2;
+            } else {
+                uint32_t npx = min(4u, W - x);
+                for (uint32_t i = 0; i < npx * 3; ++i) out[off + i] = (uint8_t)o[i];
+            }
+        }
+    }
+}
+
+/* image_ycbcr_to_rgb on a device buffer: src/image.c:39-51, same exact integer form */
+__global__ void k_ycbcr_to_rgb(uint8_t *px, size_t npix) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    int Y = px[3 * i], Cb = px[3 * i + 1], Cr = px[3 * i + 2];
+    ChromaTerms ct = chroma_terms(Cb, Cr);
+    px[3 * i] = (uint8_t)clamp255(Y + ct.dr);
+    px[3 * i + 1] = (uint8_t)clamp255(Y + ct.dg - green_fix(ct, Y));
+    px[3 * i + 2] = (uint8_t)clamp255(Y + ct.db);
+}
+
+/* ============================================================================================
+ * host side of the C ABI
+ * ========================================================================================== */
+
+struct jdgpu_batch {
+    jd_plan plan;
+    unsigned flags;
+    hipStream_t stream;
+    uint8_t *d_raw, *d_clean, *d_pix;
+    jd_image *d_img;
+    jd_lut *d_luts;
+    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_wg_exit[2], *d_status, *d_changed;
+    int4 *d_cnt, *d_start_dc;
+    int2 *d_start_blk;
+    int16_t *d_coef;
+    jd_huff_wg *d_hwg;
+    jd_pix_wg *d_pwg;
+    hipEvent_t ev[JDGPU_NSTAGES + 1];
+    float ms[JDGPU_NSTAGES];
+    std::vector<uint32_t> status;
+    uint32_t *h_changed; /* pinned */
+    int retries;
+    bool timed;
+};
+
+static std::mutex g_mu;
+static int g_device = -1;
+
+extern "C" const char *jdgpu_last_error(void) { return g_err; }
+
+extern "C" int jdgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int jdgpu_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        snprintf(g_err, sizeof g_err, "no HIP device visible: the MI355X backend has no CPU fallback");
+        return JDGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (0..%d)", device, n - 1); return JDGPU_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    if (g_device != device) {
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zz_cm), jd_zigzag_to_cm, 64));
+        g_device = device;
+    }
+    return JDGPU_OK;
+}
+
+static int ensure_device() {
+    if (g_device >= 0) { hipError_t e = hipSetDevice(g_device); (void)e; return JDGPU_OK; }
+    return jdgpu_init(0);
+}
+
+template <class T>
+static int dalloc(T **p, size_t count) {
+    *p = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
+    return JDGPU_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != JDGPU_OK) { jdgpu_batch_destroy(b); return rc_; } } while (0)
+#define HIPTRY(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call,            \
+                     hipGetErrorString(e_));                                                      \
+            jdgpu_batch_destroy(b);                                                               \
+            return JDGPU_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
+    if (!b) return;
+    hipFree(b->d_raw); hipFree(b->d_clean); hipFree(b->d_pix); hipFree(b->d_img); hipFree(b->d_luts);
+    hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_wg_exit[0]);
+    hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt);
+    hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
+    if (b->h_changed) hipHostFree(b->h_changed);
+    for (auto &e : b->ev) if (e) hipEventDestroy(e);
+    if (b->stream) hipStreamDestroy(b->stream);
+    jd_plan_free(&b->plan);
+    delete b;
+}
+
+extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out) {
+    if (!out || (!descs && n)) { snprintf(g_err, sizeof g_err, "null argument"); return JDGPU_ERR_ARG; }
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    jdgpu_batch *b = new jdgpu_batch();
+    memset(static_cast<void *>(&b->plan), 0, sizeof b->plan);
+    b->flags = flags | JDGPU_HOST_PREP; /* TODO(unstuff on GPU) */
+    b->stream = nullptr; b->h_changed = nullptr; b->retries = 0; b->timed = false;
+    b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
+    b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_wg_exit[0] = b->d_wg_exit[1] = b->d_status = b->d_changed = nullptr;
+    b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
+    for (auto &e : b->ev) e = nullptr;
+    TRY(jd_plan_build(descs, n, &b->plan, g_err, sizeof g_err));
+    jd_plan &P = b->plan;
+    b->status.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) if (!P.img[i].ncomp) b->status[i] = JDGPU_IMG_UNSUPPORTED;
+
+    HIPTRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (auto &e : b->ev) HIPTRY(hipEventCreate(&e));
+    HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_changed), 64));
+    TRY(dalloc(&b->d_raw, P.raw_bytes));
+    TRY(dalloc(&b->d_clean, P.clean_bytes));
+    TRY(dalloc(&b->d_pix, (size_t)P.pix_bytes + 256));
+    TRY(dalloc(&b->d_img, n));
+    TRY(dalloc(&b->d_luts, n * JD_LUT_SLOTS));
+    TRY(dalloc(&b->d_seg_info, (size_t)P.n_segs_cap + 1));
+    TRY(dalloc(&b->d_st_in, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_st_exit, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_cnt, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_start_dc, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_start_blk, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_wg_exit[0], (size_t)P.n_hwg));
+    TRY(dalloc(&b->d_wg_exit[1], (size_t)P.n_hwg));
+    TRY(dalloc(&b->d_status, n));
+    TRY(dalloc(&b->d_changed, 16));
+    TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
+    TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg));
+    TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
+
+    if (b->flags & JDGPU_HOST_PREP) {
+        jd_plan_unstuff_host(&P);
+        HIPTRY(hipMemcpy(b->d_clean, P.clean, P.clean_bytes, hipMemcpyHostToDevice));
+        HIPTRY(hipMemcpy(b->d_seg_info, P.seg_info, (size_t)P.n_segs_cap * 4, hipMemcpyHostToDevice));
+    }
+    HIPTRY(hipMemcpy(b->d_raw, P.raw, P.raw_bytes, hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemset(b->d_pix, 0, (size_t)P.pix_bytes + 256));
+    HIPTRY(hipMemset(b->d_status, 0, (n ? n : 1) * 4));
+    /* the host copies of the bulky arrays are not needed any more */
+    free(P.raw); P.raw = nullptr; free(P.clean); P.clean = nullptr; free(P.luts); P.luts = nullptr;
+    *out = b;
+    return JDGPU_OK;
+}
+
+static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
+    jd_plan &P = b->plan;
+    if (first_pass) {
+        hipLaunchKernelGGL(k_huff_sync, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
+                           b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[0]);
+    }
+    /* one stitching round across work-groups (more only if k_huff_write reports UNSYNCED) */
+    int src = first_pass ? 0 : (b->retries & 1);
+    hipLaunchKernelGGL(k_huff_resync, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
+                       b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[src],
+                       b->d_wg_exit[src ^ 1], b->d_changed);
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
+    if (!b) return JDGPU_ERR_ARG;
+    jd_plan &P = b->plan;
+    if (P.n == 0) return JDGPU_OK;
+    const bool prof = (b->flags & JDGPU_PROFILE) != 0;
+    b->retries = 0;
+    hipStream_t st = b->stream;
+    HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
+    HIPCHK(hipMemsetAsync(b->d_changed, 0, 64, st));
+    if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
+    /* unstuff: TODO GPU stage; host prep already uploaded the clean stream */
+    if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
+    if (P.n_hwg) enqueue_huffman(b, true);
+    if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
+    hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
+    if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
+    HIPCHK(hipMemsetAsync(b->d_coef, 0, (size_t)P.total_blocks * 128, st));
+    if (P.n_hwg)
+        hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
+                           b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+    if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
+    if (P.n_pwg) {
+        if (b->flags & JDGPU_OUT_YCBCR)
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(256), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+        else
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(256), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+    }
+    if (prof) HIPCHK(hipEventRecord(b->ev[5], st));
+    HIPCHK(hipGetLastError());
+    b->timed = prof;
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
+    if (!b) return JDGPU_ERR_ARG;
+    jd_plan &P = b->plan;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (P.n == 0) return JDGPU_OK;
+    std::vector<uint32_t> st(P.n);
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(hipMemcpy(st.data(), b->d_status, P.n * 4, hipMemcpyDeviceToHost));
+        bool unsynced = false;
+        for (size_t i = 0; i < P.n; ++i) unsynced |= (st[i] & JDGPU_IMG_UNSYNCED) != 0;
+        if (!unsynced) break;
+        if (attempt > 64 + (int)P.n_hwg) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
+        /* a change crossed a whole work-group: stitch once more, then redo scan + write + pixel */
+        ++b->retries;
+        hipStream_t s = b->stream;
+        HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, s));
+        enqueue_huffman(b, false);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
+        HIPCHK(hipMemsetAsync(b->d_coef, 0, (size_t)P.total_blocks * 128, s));
+        hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
+                           b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+        if (b->flags & JDGPU_OUT_YCBCR)
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(256), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+        else
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(256), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);
+    if (b->timed) {
+        for (int s = 0; s < 5; ++s) HIPCHK(hipEventElapsedTime(&b->ms[s], b->ev[s], b->ev[s + 1]));
+        HIPCHK(hipEventElapsedTime(&b->ms[JDGPU_STAGE_TOTAL], b->ev[0], b->ev[5]));
+    }
+    return JDGPU_OK;
+}
+
+extern "C" size_t jdgpu_batch_size(const jdgpu_batch *b) { return b ? b->plan.n : 0; }
+extern "C" uint32_t jdgpu_batch_status(const jdgpu_batch *b, size_t i) { return (b && i < b->plan.n) ? b->status[i] : ~0u; }
+extern "C" uint64_t jdgpu_batch_total_pixels(const jdgpu_batch *b) { return b ? b->plan.total_pixels : 0; }
+extern "C" uint64_t jdgpu_batch_total_blocks(const jdgpu_batch *b) { return b ? b->plan.total_blocks : 0; }
+extern "C" uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b) {
+    uint64_t t = 0;
+    if (b) for (size_t i = 0; i < b->plan.n; ++i) t += b->plan.img[i].raw_len;
+    return t;
+}
+extern "C" size_t jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i) { return (b && i < b->plan.n) ? b->plan.img[i].n_blocks : 0; }
+extern "C" int jdgpu_batch_retries(const jdgpu_batch *b) { return b ? b->retries : 0; }
+
+extern "C" void *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i) {
+    if (!b || i >= b->plan.n) return nullptr;
+    return b->d_pix + b->plan.img[i].pix_off;
+}
+
+extern "C" int jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst) {
+    if (!b || i >= b->plan.n || !dst) return JDGPU_ERR_ARG;
+    const jd_image &im = b->plan.img[i];
+    HIPCHK(hipMemcpy(dst, b->d_pix + im.pix_off, (size_t)im.width * im.height * 3, hipMemcpyDeviceToHost));
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst) {
+    if (!b || i >= b->plan.n || !dst) return JDGPU_ERR_ARG;
+    const jd_image &im = b->plan.img[i];
+    size_t nb = im.n_blocks;
+    std::vector<int16_t> tmp(nb * 64);
+    HIPCHK(hipMemcpy(tmp.data(), b->d_coef + (size_t)im.blk_off * 64, nb * 128, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < nb; ++k)
+        for (int z = 0; z < 64; ++z) dst[k * 64 + z] = tmp[k * 64 + jd_zigzag_to_cm[z]];
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]) {
+    if (!b || !ms || !b->timed) return JDGPU_ERR_ARG;
+    memcpy(ms, b->ms, sizeof b->ms);
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    size_t npix = (size_t)width * height;
+    if (!npix) return JDGPU_OK;
+    uint8_t *d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), npix * 3));
+    hipError_t e = hipMemcpy(d, host_pixels, npix * 3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_ycbcr_to_rgb, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, d, npix);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "jdgpu_ycbcr_to_rgb: %s", hipGetErrorString(e)); return JDGPU_ERR_HIP; }
+    return JDGPU_OK;
+}

@@ -1,0 +1,149 @@
+/*
+ * jdgpu_internal.h -- structures shared by the host preparation code (jdgpu_prep.c, C) and the
+ * HIP translation unit (jdgpu.hip).  Plain C; everything here is laid out for the device.
+ */
+#ifndef JDGPU_INTERNAL_H
+#define JDGPU_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "jpeg_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- bit-segment geometry ------------------------------------------------------------------
+ * The unstuffed ("clean") entropy-coded stream of an image is laid out restart interval after
+ * restart interval, each padded with 0xFF to a whole number of segments, so that every
+ * interval starts a segment with a known decoder state.  One lane decodes one segment. */
+#define JD_SEG_WORDS   32u                    /* 32-bit words per segment */
+#define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 128 B  */
+#define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 1024 b */
+#define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group */
+#define JD_MAX_BPM     12u                    /* data units per MCU: 3 components of at most 2x2 */
+#define JD_LUT_BITS    10u                    /* primary Huffman lookup width */
+#define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
+
+/* flattened Huffman table: replaces the pointer-chased tree of src/hufftree.c */
+typedef struct {
+    /* primary[peek >> (16-JD_LUT_BITS)]: bits 4:0 code length (0 = longer than JD_LUT_BITS or
+     * no such code), 8:5 magnitude size, 12:9 zero run.  DC tables: size = symbol, run = 0. */
+    uint16_t primary[1u << JD_LUT_BITS];
+    /* codes of length 11..16, canonical: with v = next 16 bits, the length is the first L
+     * with v < limit[L-11]; symbol = symbols[(v >> (16-L)) + offset[L-11]] */
+    uint32_t limit[6];
+    int32_t  offset[6];
+    uint8_t  symbols[256];
+    uint32_t is_dc;
+    uint32_t short_limit; /* 16-bit left-justified end of the codes of <= JD_LUT_BITS bits */
+    uint32_t pad[2];
+} jd_lut; /* 2048 + 24 + 24 + 256 + 16 = 2368 B, multiple of 16 */
+
+/* one lookup on the next 16 bits of the stream; shared by the kernels and the host test hook */
+#ifdef __HIPCC__
+#define JD_HD static __host__ __device__ __forceinline__
+#else
+#define JD_HD static inline
+#endif
+typedef struct { uint32_t len, size, run, bad; } jd_sym;
+JD_HD jd_sym jd_lut_lookup(const jd_lut *t, uint32_t v16) {
+    jd_sym s;
+    uint32_t e = t->primary[v16 >> (16 - JD_LUT_BITS)];
+    s.len = e & 31u; s.size = (e >> 5) & 15u; s.run = (e >> 9) & 15u; s.bad = 0;
+    if (__builtin_expect(s.len == 0, 0)) {
+        /* 11..16-bit codes: canonical ranges, the first limit above v16 gives the length */
+        uint32_t L = JD_LUT_BITS + 1;
+        for (int i = 0; i < 6; ++i) L += (v16 >= t->limit[i]) ? 1u : 0u;
+        if (L > 16 || v16 < t->short_limit) {
+            /* no code has this prefix: the reference's "Could not find next symbol in huffnode."
+             * (src/hufftree.c:69,72).  Speculative lanes must still make progress. */
+            s.len = 16; s.size = 0; s.run = 0; s.bad = 1;
+        } else {
+            uint32_t idx = (uint32_t)((int32_t)(v16 >> (16 - L)) + t->offset[L - JD_LUT_BITS - 1]) & 255u;
+            uint32_t sym = t->symbols[idx];
+            s.len = L; s.size = sym & 15u;
+            if (t->is_dc) { s.run = 0; s.bad = sym > 15u; } else { s.run = sym >> 4; }
+        }
+    }
+    return s;
+}
+
+/* per-segment word written by the unstuff stage */
+#define JD_SEG_FIRST 0x80000000u              /* first segment of a restart interval */
+/* low bits: number of valid bits in the segment (0..1024) */
+
+/* decoder state at a segment boundary, packed */
+/* bits 5:0 overshoot into the next segment, 12:6 zigzag index k (0 = expecting DC),
+ * 16:13 data unit within the MCU, 17 decode error seen */
+#define JD_ST_PACK(ovs, k, b) ((uint32_t)(ovs) | ((uint32_t)(k) << 6) | ((uint32_t)(b) << 13))
+#define JD_ST_BAD 0x20000u
+#define JD_ST_NONE 0xFFFFFFFFu
+
+typedef struct {
+    uint64_t raw_off;      /* byte offset of the stuffed scan in the raw buffer */
+    uint64_t clean_off;    /* byte offset of the clean stream (multiple of JD_SEG_BYTES) */
+    uint64_t pix_off;      /* byte offset of the output image (multiple of 256) */
+    uint64_t blk_off;      /* index of the image's first 8x8 block in the coefficient buffer */
+    uint32_t raw_len;
+    uint32_t seg_off;      /* index of the image's first segment in the per-segment arrays */
+    uint32_t seg_cap;      /* segments reserved (upper bound) */
+    uint32_t n_segs;       /* segments in use (host prep: exact; GPU unstuff: written by K0) */
+    uint32_t n_blocks;     /* data units in the scan */
+    uint32_t ri_blocks;    /* data units per restart interval, 0 = no restart markers */
+    uint32_t n_intervals;
+    uint32_t ivl_off;      /* index of the image's first interval in the interval arrays */
+    uint32_t lut_off;      /* index of the image's first jd_lut (JD_LUT_SLOTS each) */
+    uint32_t mcus_x, mcus_y;
+    uint16_t width, height;
+    uint8_t  ncomp, bpm, maxH, maxV;
+    uint8_t  blk_comp[JD_MAX_BPM];  /* scan-component index of data unit b of an MCU */
+    uint8_t  blk_h[JD_MAX_BPM];     /* its h, v position inside the component's MCU area */
+    uint8_t  blk_v[JD_MAX_BPM];
+    uint8_t  blk_dc[JD_MAX_BPM];    /* lut slot of its DC / AC table */
+    uint8_t  blk_ac[JD_MAX_BPM];
+    uint8_t  comp_H[4], comp_V[4], comp_chan[4], comp_tq[4];
+    uint8_t  pad_[2];
+    uint16_t quant[4][64];          /* dequantisation tables re-ordered for the pixel kernel:
+                                       index = col*8 + row (column-major natural order) */
+} jd_image; /* keep a multiple of 8 bytes */
+
+/* work descriptors: one per work-group */
+typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* JD_WG_SEGS segments from seg0 */
+typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of an MCU row */
+
+#define JD_STRIP_PX 256u  /* pixel-kernel strip width */
+
+/* ---- host preparation (jdgpu_prep.c) -------------------------------------------------------- */
+
+typedef struct {
+    size_t n;
+    jd_image *img;           /* [n] */
+    jd_lut *luts;            /* [n * JD_LUT_SLOTS] */
+    uint8_t *raw;            /* concatenated stuffed scans, each padded to 16 B */
+    size_t raw_bytes;
+    size_t clean_bytes;      /* capacity of the clean stream buffer */
+    uint32_t n_segs_cap;     /* total segment capacity */
+    uint32_t n_intervals;    /* total */
+    jd_huff_wg *hwg; uint32_t n_hwg;
+    jd_pix_wg *pwg;  uint32_t n_pwg;
+    uint64_t total_pixels, total_blocks, pix_bytes;
+    /* filled only by jd_prep_unstuff_host (JDGPU_HOST_PREP) */
+    uint8_t *clean;          /* [clean_bytes] */
+    uint32_t *seg_info;      /* [n_segs_cap] */
+} jd_plan;
+
+int  jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *plan, char *err, size_t errlen);
+void jd_plan_unstuff_host(jd_plan *plan);
+void jd_plan_free(jd_plan *plan);
+int  jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut);
+uint32_t jd_unstuff_image(const uint8_t *src, size_t raw_len, int use_rst, uint32_t n_intervals,
+                          uint8_t *dst, uint32_t *seg_info);
+
+extern const uint8_t jd_zigzag_to_cm[64];   /* zigzag k -> col*8+row */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+/*
+ * jdgpu_prep.c -- host-side preparation of a decode batch (plain C, no HIP).
+ *
+ * Turns n jdgpu_image_desc into device-ready flat arrays: per-image geometry records,
+ * flattened Huffman lookup tables (replacing the tree walk of the reference's
+ * src/hufftree.c:64-78; canonical code assignment as in src/hufftree.c:46-59), dequantisation
+ * tables re-ordered for the pixel kernel, the concatenated scan bytes and the work-group
+ * descriptors of the Huffman and pixel kernels.
+ *
+ * jd_plan_unstuff_host() is the host statement of the unstuff stage (src/bitstream.c:7-18
+ * plus restart-marker splitting).  The product runs that stage on the GPU (k_unstuff_* in
+ * jdgpu.hip); this one exists for JDGPU_HOST_PREP debugging and as the structure the GPU
+ * stage is checked against.
+ */
+#include "jdgpu_internal.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+const uint8_t jd_zigzag_to_cm[64] = {
+    /* zigzag position k -> col*8+row of the natural position (walk of the anti-diagonals,
+     * T.81 figure A.6; same order the reference tabulates in src/decoding.c:9-18) */
+    0,  8,  1,  2,  9,  16, 24, 17, 10, 3,  4,  11, 18, 25, 32, 40, 33, 26, 19, 12, 5,  6,
+    13, 20, 27, 34, 41, 48, 56, 49, 42, 35, 28, 21, 14, 7,  15, 22, 29, 36, 43, 50, 57, 58,
+    51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63};
+
+static void seterr(char *err, size_t n, const char *msg) {
+    if (err && n) snprintf(err, n, "%s", msg);
+}
+
+/* ---- Huffman flattening ---------------------------------------------------------------------- */
+
+int jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut) {
+    memset(lut, 0, sizeof *lut);
+    lut->is_dc = (uint32_t)is_dc;
+    memcpy(lut->symbols, spec->symbols, 256);
+    uint32_t code = 0; /* src/hufftree.c:47: codeValue */
+    int k = 0;
+    const unsigned PB = JD_LUT_BITS;
+    for (unsigned L = 1; L <= 16; ++L) {
+        unsigned cnt = spec->counts[L - 1];
+        if (L == PB + 1) lut->short_limit = code << (16 - L) > 65536u ? 65536u : code << (16 - L);
+        if (L > PB) {
+            /* canonical ranges are contiguous and increasing with L in left-justified space */
+            uint64_t lim = ((uint64_t)code + cnt) << (16 - L);
+            lut->limit[L - PB - 1] = lim > 65536 ? 65536u : (uint32_t)lim;
+            lut->offset[L - PB - 1] = k - (int32_t)code;
+        }
+        for (unsigned i = 0; i < cnt; ++i, ++code, ++k) {
+            if (k >= 256) return -1;
+            if (L > PB) continue;
+            if (code >= (1u << L)) return -1; /* over-subscribed table */
+            unsigned sym = spec->symbols[k];
+            unsigned size = is_dc ? sym : (sym & 15u), run = is_dc ? 0u : (sym >> 4);
+            if (is_dc && sym > 15) continue; /* no such magnitude category: leave invalid */
+            uint16_t e = (uint16_t)(L | (size << 5) | (run << 9));
+            uint32_t lo = code << (PB - L), n = 1u << (PB - L);
+            for (uint32_t j = 0; j < n; ++j) lut->primary[lo + j] = e;
+        }
+        code <<= 1;
+    }
+    return 0;
+}
+
+/* ---- plan -------------------------------------------------------------------------------------- */
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err, size_t errlen) {
+    memset(P, 0, sizeof *P);
+    P->n = n;
+    P->img = calloc(n ? n : 1, sizeof *P->img);
+    P->luts = calloc((n ? n : 1) * JD_LUT_SLOTS, sizeof *P->luts);
+    if (!P->img || !P->luts) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+
+    size_t raw = 0, clean = 0, pix = 0;
+    uint64_t blk = 0;
+    uint32_t segs = 0, ivls = 0, nh = 0, np = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const jdgpu_image_desc *d = &descs[i];
+        jd_image *im = &P->img[i];
+        int ok = d->ncomp == 3 && d->width && d->height && d->scan_len < 0xFFFFFF00u;
+        unsigned seen = 0, maxH = 0, maxV = 0;
+        for (unsigned c = 0; ok && c < 3; ++c) {
+            unsigned id = d->comp[c].id;
+            if (id < 1 || id > 3 || (seen >> id & 1)) ok = 0; /* channel = id-1, SURVEY 8(c) */
+            seen |= 1u << id;
+            if (d->comp[c].H < 1 || d->comp[c].H > 2 || d->comp[c].V < 1 || d->comp[c].V > 2) ok = 0;
+            if (d->comp[c].Tq > 3 || d->comp[c].Td > 3 || d->comp[c].Ta > 3) ok = 0;
+            if (ok && (!d->huff_defined[0][d->comp[c].Td] || !d->huff_defined[1][d->comp[c].Ta])) ok = 0;
+            if (d->comp[c].H > maxH) maxH = d->comp[c].H;
+            if (d->comp[c].V > maxV) maxV = d->comp[c].V;
+        }
+        im->width = d->width; im->height = d->height;
+        im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
+        im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
+        pix += align_up((size_t)d->width * d->height * 3, 256);
+        P->total_pixels += (uint64_t)d->width * d->height;
+        if (!ok) { /* marked unsupported: no segments, no work-groups, pixels stay zero */
+            im->ncomp = 0;
+            continue;
+        }
+        im->ncomp = 3; im->maxH = (uint8_t)maxH; im->maxV = (uint8_t)maxV;
+        /* lookup tables: slot per distinct (class,id) in order of first use */
+        int slot_of[2][4]; memset(slot_of, -1, sizeof slot_of);
+        unsigned nslots = 0, b = 0;
+        for (unsigned c = 0; c < 3; ++c) {
+            unsigned td = d->comp[c].Td, ta = d->comp[c].Ta;
+            if (slot_of[0][td] < 0) {
+                slot_of[0][td] = (int)nslots;
+                if (jd_lut_build(&d->huff[0][td], 1, &P->luts[im->lut_off + nslots])) ok = 0;
+                ++nslots;
+            }
+            if (slot_of[1][ta] < 0) {
+                slot_of[1][ta] = (int)nslots;
+                if (jd_lut_build(&d->huff[1][ta], 0, &P->luts[im->lut_off + nslots])) ok = 0;
+                ++nslots;
+            }
+            im->comp_H[c] = d->comp[c].H; im->comp_V[c] = d->comp[c].V;
+            im->comp_chan[c] = (uint8_t)(d->comp[c].id - 1); im->comp_tq[c] = d->comp[c].Tq;
+            for (unsigned v = 0; v < d->comp[c].V; ++v)       /* src/jpeg.c:80-81: v outer, h inner */
+                for (unsigned h = 0; h < d->comp[c].H; ++h, ++b) {
+                    im->blk_comp[b] = (uint8_t)c; im->blk_h[b] = (uint8_t)h; im->blk_v[b] = (uint8_t)v;
+                    im->blk_dc[b] = (uint8_t)slot_of[0][td]; im->blk_ac[b] = (uint8_t)slot_of[1][ta];
+                }
+        }
+        if (!ok) { im->ncomp = 0; continue; }
+        im->bpm = (uint8_t)b;
+        for (unsigned t = 0; t < 4; ++t)
+            for (unsigned k = 0; k < 64; ++k) im->quant[t][jd_zigzag_to_cm[k]] = d->quant[t][k];
+        im->mcus_x = (d->width + 8u * maxH - 1) / (8u * maxH);   /* src/jpeg.c:66-75 */
+        im->mcus_y = (d->height + 8u * maxV - 1) / (8u * maxV);
+        uint32_t nmcu = im->mcus_x * im->mcus_y;
+        im->n_blocks = nmcu * b;
+        uint32_t ri = d->restart_interval;
+        im->ri_blocks = ri ? ri * b : 0;
+        im->n_intervals = ri ? (nmcu + ri - 1) / ri : 1;
+        im->raw_len = (uint32_t)d->scan_len;
+        im->seg_cap = (uint32_t)((d->scan_len + JD_SEG_BYTES - 1) / JD_SEG_BYTES) + im->n_intervals;
+        raw += align_up(d->scan_len + 16, 16);
+        clean += (size_t)im->seg_cap * JD_SEG_BYTES;
+        segs += im->seg_cap; ivls += im->n_intervals; blk += im->n_blocks;
+        nh += (im->seg_cap + JD_WG_SEGS - 1) / JD_WG_SEGS;
+        uint32_t strip = JD_STRIP_PX / (8u * maxH);
+        np += im->mcus_y * ((im->mcus_x + strip - 1) / strip);
+    }
+    P->raw_bytes = raw + 64; P->clean_bytes = clean + JD_SEG_BYTES * 2;
+    P->n_segs_cap = segs; P->n_intervals = ivls; P->total_blocks = blk; P->pix_bytes = pix;
+    P->n_hwg = nh; P->n_pwg = np;
+    P->raw = calloc(P->raw_bytes, 1);
+    P->hwg = calloc(nh ? nh : 1, sizeof *P->hwg);
+    P->pwg = calloc(np ? np : 1, sizeof *P->pwg);
+    if (!P->raw || !P->hwg || !P->pwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+    nh = np = 0;
+    for (size_t i = 0; i < n; ++i) {
+        jd_image *im = &P->img[i];
+        if (!im->ncomp) continue;
+        memcpy(P->raw + im->raw_off, descs[i].scan, descs[i].scan_len);
+        for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
+        uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
+        for (uint32_t r = 0; r < im->mcus_y; ++r)
+            for (uint32_t c = 0; c < im->mcus_x; c += strip) {
+                P->pwg[np].img = (uint32_t)i; P->pwg[np].mcu_row = (uint16_t)r; P->pwg[np].mcu_col0 = (uint16_t)c; ++np;
+            }
+    }
+    return JDGPU_OK;
+}
+
+/* ---- host statement of the unstuff stage --------------------------------------------------------
+ * Reference semantics (src/bitstream.c:11-14): a 0xFF that is read as data stays in the stream
+ * and the byte after it is dropped whatever its value.  Restart extension: with a restart
+ * interval, 0xFF 0xD0..0xD7 is a marker -- both bytes go, and the next interval starts. */
+uint32_t jd_unstuff_image(const uint8_t *src, size_t raw_len, int use_rst, uint32_t n_intervals,
+                          uint8_t *dst, uint32_t *si) {
+    uint32_t seg = 0, ivl = 0;
+    size_t o = 0, ivl_start = 0, p = 0; /* o: write offset in dst */
+    for (;;) {
+        int at_end = p >= raw_len;
+        int marker = !at_end && use_rst && src[p] == 0xFF && p + 1 < raw_len &&
+                     src[p + 1] >= 0xD0 && src[p + 1] <= 0xD7 && ivl + 1 < n_intervals;
+        if (at_end || marker) {
+            /* close the interval: pad to a segment boundary, emit its segment words */
+            size_t len = o - ivl_start;
+            uint32_t ns = (uint32_t)((len + JD_SEG_BYTES - 1) / JD_SEG_BYTES);
+            if (ns == 0) ns = 1;
+            for (uint32_t s = 0; s < ns; ++s) {
+                size_t bits = len * 8 > (size_t)s * JD_SEG_BITS ? len * 8 - (size_t)s * JD_SEG_BITS : 0;
+                si[seg + s] = (uint32_t)(bits > JD_SEG_BITS ? JD_SEG_BITS : bits) | (s == 0 ? JD_SEG_FIRST : 0);
+            }
+            seg += ns;
+            for (size_t q = o; q < ivl_start + (size_t)ns * JD_SEG_BYTES; ++q) dst[q] = 0xFF;
+            o = ivl_start + (size_t)ns * JD_SEG_BYTES;
+            ivl_start = o;
+            ++ivl;
+            if (at_end) break;
+            p += 2;
+            continue;
+        }
+        uint8_t c = src[p++];
+        dst[o++] = c;
+        if (c == 0xFF) ++p; /* drop the follower */
+    }
+    return seg;
+}
+
+void jd_plan_unstuff_host(jd_plan *P) {
+    free(P->clean); free(P->seg_info);
+    P->clean = malloc(P->clean_bytes);
+    P->seg_info = calloc(P->n_segs_cap ? P->n_segs_cap : 1, sizeof *P->seg_info);
+    memset(P->clean, 0xFF, P->clean_bytes);
+    for (size_t i = 0; i < P->n; ++i) {
+        jd_image *im = &P->img[i];
+        if (!im->ncomp) continue;
+        im->n_segs = jd_unstuff_image(P->raw + im->raw_off, im->raw_len, im->ri_blocks != 0, im->n_intervals,
+                                      P->clean + im->clean_off, P->seg_info + im->seg_off);
+    }
+}
+
+/* ---- host test hooks (declared in include/jpeg_gpu.h) ----------------------------------------- */
+
+int jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, unsigned *len,
+                          unsigned *run, unsigned *size) {
+    jd_lut lut;
+    if (jd_lut_build(spec, is_dc, &lut)) return -2;
+    jd_sym s = jd_lut_lookup(&lut, v16 & 0xFFFFu);
+    *len = s.len; *run = s.run; *size = s.size;
+    return s.bad ? -1 : 0;
+}
+
+long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
+                        uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap) {
+    size_t need = (len + JD_SEG_BYTES - 1) / JD_SEG_BYTES + (n_intervals ? n_intervals : 1);
+    if (seg_cap < need || clean_cap < need * JD_SEG_BYTES) return -1;
+    return (long)jd_unstuff_image(scan, len, (int)use_rst, n_intervals ? n_intervals : 1, clean, seg_info);
+}
+
+void jd_plan_free(jd_plan *P) {
+    free(P->img); free(P->luts); free(P->raw); free(P->hwg); free(P->pwg);
+    free(P->clean); free(P->seg_info);
+    memset(P, 0, sizeof *P);
+}

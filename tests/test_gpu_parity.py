@@ -1,0 +1,204 @@
+"""GPU (-m gpu): the HIP path through the C ABI against the oracle and the reference's golden
+vectors.  Bar: coefficients bit-exact; pixels within +-1 LSB per channel (BASELINE.json), and in
+fact byte-identical on every fixture (the pixel kernel evaluates the same doubles)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, all_golden_names, dri_names, golden_arrays, golden_stream, load_pkg, plain_names
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1  # LSB per channel, BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def dec(pkg):
+    return pkg.Decoder(0)
+
+
+def _check_against_oracle(pkg, oracle, out, i, data, exact=True):
+    assert out.status(i) == 0
+    rc, info, q = oracle.qcoef(data)
+    assert rc == 0
+    got_q = out.qcoef(i)
+    assert got_q.shape == q.shape
+    assert np.array_equal(got_q.astype(np.int32), q), "coefficients differ"
+    want = oracle.to_rgb(oracle.pixels_from_qcoef(info, q))
+    got = out.rgb(i)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= RGB_TOL, f"max |dRGB| = {d.max()}"
+    if exact:
+        assert np.array_equal(got, want), f"{int((d > 0).sum())} channel values differ by 1"
+
+
+@pytest.mark.parametrize("name", plain_names())
+def test_golden_vectors(pkg, dec, oracle, manifest, name):
+    """every fixture the unmodified reference produced (tests/golden, oracle/gen_golden.py)"""
+    data = golden_stream(name)
+    coef, ycc, rgb = golden_arrays(name)
+    out = dec.decode([data])
+    assert out.status(0) == 0 and out.retries == 0
+    rc, info, _ = oracle.qcoef(data)
+    got_q = out.qcoef(0)
+    # reference's dequantised natural-order blocks == ours after dequant + un-zigzag
+    assert np.array_equal(oracle.dequant_natural(info, got_q.astype(np.int32)), coef)
+    got = out.rgb(0)
+    d = np.abs(got.astype(np.int16) - rgb.astype(np.int16))
+    assert d.max() <= RGB_TOL
+    assert hashlib.md5(got.tobytes()).hexdigest() == manifest[name]["md5_rgb"]
+    ycc_out = dec.decode([data], flags=pkg.OUT_YCBCR)
+    assert hashlib.md5(ycc_out.pixels(0).tobytes()).hexdigest() == manifest[name]["md5_ycbcr"]
+
+
+@pytest.mark.parametrize("name", dri_names())
+def test_restart_streams_equal_their_twins(pkg, dec, oracle, manifest, name):
+    twin = manifest[name]["twin"]
+    out = dec.decode([golden_stream(name), golden_stream(twin)])
+    assert out.status(0) == 0 and out.status(1) == 0
+    assert np.array_equal(out.qcoef(0), out.qcoef(1))
+    assert np.array_equal(out.rgb(0), out.rgb(1))
+    assert hashlib.md5(out.rgb(0).tobytes()).hexdigest() == manifest[twin]["md5_rgb"]
+
+
+def test_mixed_batch(pkg, dec, oracle, manifest):
+    """all fixtures in one batch, twice over (ragged sizes, 4:2:0 + 4:4:4 + DRI interleaved)"""
+    names = all_golden_names() * 2
+    out = dec.decode([golden_stream(n) for n in names])
+    for i, n in enumerate(names):
+        ref = manifest[n]["twin"] if manifest[n]["dri"] else n
+        assert out.status(i) == 0
+        assert hashlib.md5(out.rgb(i).tobytes()).hexdigest() == manifest[ref]["md5_rgb"], n
+    # decoding the same resident batch again is idempotent
+    first = [out.rgb(i).copy() for i in range(len(names))]
+    out.decode()
+    for i in range(len(names)):
+        assert np.array_equal(out.rgb(i), first[i])
+
+
+def test_empty_batch(pkg, dec):
+    out = dec.decode([])
+    assert out.n == 0 and out.total_pixels == 0
+
+
+def test_exhaustive_colour(pkg, dec, oracle):
+    """image_ycbcr_to_rgb on the GPU over all 2^24 (Y,Cb,Cr) == src/image.c:39-51 (oracle)"""
+    y, cb, cr = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    img = np.stack([y, cb, cr], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(pkg.ycbcr_to_rgb(img), oracle.to_rgb(img))
+
+
+def test_cli_reproduces_reference_stdout(manifest):
+    """config 1 of BASELINE.json: the demo viewer on birb.jpg, byte-identical terminal dump"""
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
+    for name in ("ex_birb", "ex_no_subsampling_skyline"):
+        r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "streams", name + ".jpg")],
+                           capture_output=True, check=True)
+        assert hashlib.md5(r.stdout).hexdigest() == manifest[name]["md5_cli_stdout"]
+
+
+SHAPES = [(16, 16), (8, 8), (24, 40), (200, 200), (642, 482), (1000, 10), (24, 1000), (1280, 720), (322, 242)]
+
+
+@pytest.mark.parametrize("ss", [0, 1])
+def test_seeded_synthetic_vs_oracle(pkg, dec, oracle, ss):
+    """seeded synthetic streams, ragged sizes (incl. non-multiples of the MCU and of 4),
+    qualities 20..98, with and without restart markers, decoded as ONE batch"""
+    rng = np.random.default_rng(100 + ss)
+    files = []
+    for i, (w, h) in enumerate(SHAPES):
+        if ss == 1 and (w % 2 or h % 2):
+            continue  # odd sizes with subsampling are outside the reference's contract
+        q = int(rng.integers(20, 99))
+        mcux = -(-w // (16 if ss else 8))
+        for ri in (0, 1, mcux, 3 * mcux + 1):
+            files.append(pkg.synth.make_jpeg(w, h, seed=1000 + i, quality=q, subsamp=ss, restart_mcus=ri))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+
+
+def test_noise_images_long_codes(pkg, dec, oracle):
+    """white-noise pixels at quality 100: dense blocks, 16-bit codes, ZRL runs, segments that
+    hold less than one data unit"""
+    rng = np.random.default_rng(7)
+    files = []
+    for ss in (0, 1):
+        rgb = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+        for ri in (0, 4):
+            files.append(pkg.synth.encode_rgb(rgb, quality=100, subsamp=ss, restart_mcus=ri))
+    flat = np.full((64, 64, 3), 77, np.uint8)   # all-EOB blocks: many data units per segment
+    files.append(pkg.synth.encode_rgb(flat, quality=50, subsamp=1))
+    files.append(pkg.synth.encode_rgb(flat, quality=50, subsamp=0, restart_mcus=2))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+
+
+def test_full_size_1080p(pkg, dec, oracle):
+    """BASELINE config 3 shape: 1920x1080 4:2:0, ~2900 segments, 12 work-groups to stitch"""
+    plain = pkg.synth.make_jpeg(1920, 1080, seed=1234, quality=85, subsamp=1)
+    dri = pkg.synth.make_jpeg(1920, 1080, seed=1234, quality=85, subsamp=1, restart_mcus=120)
+    out = dec.decode([plain, dri, plain])
+    _check_against_oracle(pkg, oracle, out, 0, plain)
+    assert np.array_equal(out.qcoef(1), out.qcoef(0)) and np.array_equal(out.rgb(1), out.rgb(0))
+    assert np.array_equal(out.rgb(2), out.rgb(0))
+
+
+def test_full_size_4k_restart_rows(pkg, dec, oracle):
+    """BASELINE config 4 shape: 3840x2160 4:2:0, DRI = one MCU row; size-independent property:
+    identical output to the same pixels encoded without restart markers"""
+    dri = pkg.synth.make_jpeg(3840, 2160, seed=99, quality=85, subsamp=1, restart_mcus=240)
+    plain = pkg.synth.make_jpeg(3840, 2160, seed=99, quality=85, subsamp=1)
+    out = dec.decode([dri, plain])
+    assert out.status(0) == 0 and out.status(1) == 0
+    assert np.array_equal(out.qcoef(0), out.qcoef(1))
+    assert np.array_equal(out.rgb(0), out.rgb(1))
+    rc, info, q = oracle.qcoef(dri)
+    assert np.array_equal(out.qcoef(0).astype(np.int32), q)
+
+
+def test_error_status_matches_oracle(pkg, dec, oracle):
+    """truncated and corrupted scans: same failure class as the reference's FAIL sites
+    (src/bitstream.c:17 EOF, src/hufftree.c:69,72 no symbol); good images in the same batch
+    are unaffected"""
+    good = golden_stream("syn_200x136_420_q50")
+    off = oracle.parse(good)[1].scan_offset
+    cut = good[:off + (len(good) - off) // 3]
+    rng = np.random.default_rng(3)
+    junk = bytearray(good)
+    junk[off + 50:off + 400] = bytes(rng.integers(0, 255, 350, dtype=np.uint8))
+    junk = bytes(junk)
+    out = dec.decode([good, cut, junk, good])
+    assert out.status(0) == 0 and out.status(3) == 0
+    assert np.array_equal(out.rgb(0), out.rgb(3))
+    want = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}
+    for i, f in ((1, cut), (2, junk)):
+        rc = oracle.qcoef(f)[0]
+        if rc == 0:
+            assert out.status(i) == 0
+            assert np.array_equal(out.qcoef(i).astype(np.int32), oracle.qcoef(f)[2])
+        else:
+            assert out.status(i) & want[rc], (i, rc, out.status(i))
+
+
+def test_unsupported_layout_is_reported_not_decoded(pkg, dec):
+    d = pkg.parse(golden_stream("syn_8x8_444_q85"))
+    d.comp[0].id = 7   # channel = id-1 would be out of range (src/decoding.c:107)
+    out = pkg.Batch([d, pkg.parse(golden_stream("syn_8x8_444_q85"))]).decode()
+    assert out.status(0) == pkg.IMG_UNSUPPORTED and out.status(1) == 0
+
+
+def test_stage_timers(pkg, dec):
+    b = dec.batch([golden_stream("syn_640x360_420_q85")] * 8, flags=pkg.PROFILE)
+    b.decode()
+    ms = b.stage_ms()
+    assert ms["total"] > 0 and ms["pixel"] > 0 and ms["sync"] > 0

@@ -1,0 +1,329 @@
+"""CPU: the drop-in boundary (include/*.h, libjpegamd.so) and the host-side logic, no GPU
+compute.  Mirrors what the reference's callers rely on (src/test.c:21-45) and SURVEY.md 8(b)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, all_golden_names, golden_stream, load_pkg
+
+INC = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def declared_functions():
+    names = set()
+    for h in ("jpeg.h", "image.h", "jpeg_gpu.h"):
+        src = open(os.path.join(INC, h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b((?:jdgpu|jpeg|image)_[a-z_0-9]+)\s*\(", src))
+    names.discard("image_size")  # macro
+    return names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = C.CDLL(pkg.LIB_PATH)
+    decl = declared_functions()
+    assert decl == set(pkg.EXPORTS), decl ^ set(pkg.EXPORTS)
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+
+
+def test_struct_layout_matches_reference(tmp_path):
+    """sizes/offsets recorded in SURVEY.md 8(b) for the reference's jpeg.h (measured there)."""
+    prog = tmp_path / "layout.c"
+    prog.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "jpeg.h"\n'
+                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(jpeg_info),'
+                    'offsetof(jpeg_info, quantizationTables), offsetof(jpeg_info, huffmanTables),'
+                    'offsetof(jpeg_info, width), offsetof(jpeg_info, height), offsetof(jpeg_info, precision),'
+                    'sizeof(scan_info), sizeof(huffnode), sizeof(pixel));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", INC, str(prog), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert list(map(int, out)) == [1224, 768, 1024, 1216, 1218, 1220, 15, 24, 3]
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_header_parse_matches_oracle(pkg, oracle, name):
+    data = golden_stream(name)
+    d = pkg.parse(data)
+    rc, info = oracle.parse(data)
+    assert rc == 0
+    assert (d.width, d.height, d.ncomp) == (info.width, info.height, info.ncomp)
+    assert d.restart_interval == info.restart_interval
+    assert d.scan_len == len(data) - info.scan_offset
+    for i in range(d.ncomp):
+        cid = info.scomp[i].id
+        assert (d.comp[i].id, d.comp[i].Td, d.comp[i].Ta) == (cid, info.scomp[i].Td, info.scomp[i].Ta)
+        assert (d.comp[i].H, d.comp[i].V, d.comp[i].Tq) == (info.comp[cid].H, info.comp[cid].V, info.comp[cid].Tq)
+    for t in range(4):
+        assert bytes(d.quant[t]) == bytes(info.quant[t])
+    for c in range(2):
+        for t in range(4):
+            assert bool(d.huff_defined[c][t]) == bool(info.huff[c][t].defined)
+            if info.huff[c][t].defined:
+                n = info.huff[c][t].nsymbols
+                assert bytes(d.huff[c][t].counts) == bytes(info.huff[c][t].counts)
+                assert bytes(d.huff[c][t].symbols)[:n] == bytes(info.huff[c][t].symbols)[:n]
+
+
+def test_header_rejections(pkg, oracle):
+    """same -1 cases as the reference's parsers (src/jpeg.c:25-54, src/parsing.c)"""
+    good = golden_stream("syn_8x8_444_q85")
+    cases = []
+    b = bytearray(good); b[1] = 0xD9; cases.append(bytes(b))                 # not SOI
+    cases.append(good[:40])                                                   # short payload read
+    i = good.index(b"\xff\xc0")
+    b = bytearray(good); b[i + 4] = 12; cases.append(bytes(b))               # precision 12
+    b = bytearray(good); b[i + 5] = b[i + 6] = 0; cases.append(bytes(b))     # height 0 (DNL)
+    b = bytearray(good); b[i + 11] = 0x51; cases.append(bytes(b))            # H sampling 5
+    b = bytearray(good); b[i + 12] = 4; cases.append(bytes(b))               # Tq 4
+    j = good.index(b"\xff\xdb")
+    b = bytearray(good); b[j + 4] = 0x10; cases.append(bytes(b))             # 16-bit DQT
+    k = good.index(b"\xff\xc4")
+    b = bytearray(good); b[k + 4] = 0x24; cases.append(bytes(b))             # DHT class 2
+    s = good.index(b"\xff\xda")
+    b = bytearray(good); b[s + 6] = 0x40; cases.append(bytes(b))             # Td 4
+    b = bytearray(good); b[s + 3] = 11; cases.append(bytes(b))               # SOS length mismatch
+    for c in cases:
+        assert oracle.parse(c)[0] == -1
+        with pytest.raises(pkg.JpegError):
+            pkg.parse(c)
+
+
+def _canonical_decode(counts, symbols, v16):
+    """bit-by-bit canonical walk (the tree of src/hufftree.c:46-59 as first/count per length)"""
+    code, first, k = 0, 0, 0
+    for L in range(1, 17):
+        code = (code << 1) | ((v16 >> (16 - L)) & 1)
+        n = counts[L - 1]
+        if code - first < n:
+            return L, symbols[k + code - first]
+        k += n
+        first = (first + n) << 1
+    return None
+
+
+def test_flattened_tables_equal_tree_walk(pkg):
+    """every 16-bit window of every distinct table in the fixtures: the flattened lookup the
+    kernels use == the bitwise code walk (test pyramid item 1)"""
+    L = pkg.lib()
+    seen = {}
+    for name in all_golden_names():
+        d = pkg.parse(golden_stream(name))
+        for c in range(2):
+            for t in range(4):
+                if d.huff_defined[c][t]:
+                    key = (c, bytes(d.huff[c][t].counts), bytes(d.huff[c][t].symbols))
+                    seen[key] = d.huff[c][t]
+    assert len(seen) >= 8
+    ln, run, size = C.c_uint(), C.c_uint(), C.c_uint()
+    maxlen = 0
+    for (cls, counts, symbols), spec in seen.items():
+        step = 1 if max(i + 1 for i in range(16) if counts[i]) > 12 else 3
+        for v in range(0, 65536, step):
+            rc = L.jdgpu_host_lut_lookup(C.byref(spec), int(cls == 0), v, C.byref(ln), C.byref(run), C.byref(size))
+            want = _canonical_decode(counts, symbols, v)
+            if want is None:
+                assert rc == -1
+                continue
+            wl, sym = want
+            maxlen = max(maxlen, wl)
+            assert rc == 0 and ln.value == wl
+            if cls == 0:
+                assert (run.value, size.value) == (0, sym)
+            else:
+                assert (run.value, size.value) == (sym >> 4, sym & 15)
+    assert maxlen == 16  # the fixtures exercise the long-code path
+
+
+def _ref_reader_bytes(scan):
+    """the reference's byte reader (src/bitstream.c:7-18): data bytes in the order they are used"""
+    out, i = bytearray(), 0
+    while i < len(scan):
+        out.append(scan[i])
+        i += 2 if scan[i] == 0xFF else 1
+    return bytes(out)
+
+
+def _unstuff(pkg, scan, use_rst=0, n_intervals=1):
+    L = pkg.lib()
+    cap = len(scan) // 128 + n_intervals + 2
+    clean = np.zeros(cap * 128, np.uint8)
+    seg = np.zeros(cap, np.uint32)
+    src = np.frombuffer(bytes(scan) + b"\0", np.uint8)
+    n = L.jdgpu_host_unstuff(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(scan), use_rst, n_intervals,
+                             clean.ctypes.data_as(C.POINTER(C.c_uint8)), clean.size,
+                             seg.ctypes.data_as(C.POINTER(C.c_uint32)), seg.size)
+    assert n >= 1
+    return clean[:n * 128], seg[:n]
+
+
+def test_unstuff_matches_reference_reader(pkg, oracle):
+    for name in all_golden_names():
+        data = golden_stream(name)
+        off = oracle.parse(data)[1].scan_offset
+        scan = data[off:]
+        clean, seg = _unstuff(pkg, scan)
+        want = _ref_reader_bytes(scan)
+        nbits = int((seg & 0x7FF).sum())
+        assert nbits == 8 * len(want)
+        assert bytes(clean[:len(want)]) == want
+        assert np.all(clean[len(want):] == 0xFF)           # padding
+        assert seg[0] >> 31 == 1 and np.all(seg[1:] >> 31 == 0)
+
+
+def test_unstuff_tail_and_ff_runs(pkg):
+    # birb.jpg ends "... FF 00 FF D9": the stuffed byte is the last data byte
+    clean, seg = _unstuff(pkg, bytes([0x12, 0xFF, 0x00, 0xFF, 0xD9]))
+    assert bytes(clean[:3]) == bytes([0x12, 0xFF, 0xFF]) and (seg[0] & 0x7FF) == 24
+    # FF FF FF 41: first FF data, second dropped, third data, 0x41 dropped
+    clean, seg = _unstuff(pkg, bytes([0xFF, 0xFF, 0xFF, 0x41, 0x07]))
+    assert bytes(clean[:3]) == bytes([0xFF, 0xFF, 0x07]) and (seg[0] & 0x7FF) == 24
+    # trailing lone FF
+    clean, seg = _unstuff(pkg, bytes([0x01, 0xFF]))
+    assert bytes(clean[:2]) == bytes([0x01, 0xFF]) and (seg[0] & 0x7FF) == 16
+
+
+def test_unstuff_restart_split(pkg):
+    a, b, c = bytes(range(1, 200)), bytes([0x55, 0xFF, 0x00, 0x66]), b""
+    scan = a + b"\xff\xd0" + b + b"\xff\xd1" + c + b"\xff\xd2" + bytes([9, 9])
+    clean, seg = _unstuff(pkg, scan, use_rst=1, n_intervals=4)
+    firsts = np.nonzero(seg >> 31)[0]
+    assert list(firsts) == [0, 2, 3, 4] and len(seg) == 5
+    assert list(seg & 0x7FF) == [1024, (199 - 128) * 8, 3 * 8, 0, 16]
+    assert bytes(clean[:199]) == a and bytes(clean[256:259]) == bytes([0x55, 0xFF, 0x66])
+    assert bytes(clean[512:514]) == bytes([9, 9])
+    # without a restart interval FF D0 is "data FF + dropped byte" like any other (src/bitstream.c:11-14)
+    clean2, seg2 = _unstuff(pkg, scan, use_rst=0, n_intervals=1)
+    assert bytes(clean2[:int((seg2 & 0x7FF).sum()) // 8]) == _ref_reader_bytes(scan)
+    # more markers than intervals: the surplus is treated as data
+    clean3, seg3 = _unstuff(pkg, scan, use_rst=1, n_intervals=2)
+    assert int((seg3 >> 31).sum()) == 2
+
+
+class _HuffNode(C.Structure):
+    pass
+
+
+_HuffNode._fields_ = [("left", C.POINTER(_HuffNode)), ("right", C.POINTER(_HuffNode)), ("symbol", C.c_uint8),
+                      ("hasLeft", C.c_bool), ("hasRight", C.c_bool), ("hasSymbol", C.c_bool)]
+
+
+class _JpegInfo(C.Structure):
+    _fields_ = [("componentInfo", (C.c_uint8 * 3) * 256), ("quantizationTables", (C.c_uint8 * 64) * 4),
+                ("huffmanTables", (_HuffNode * 4) * 2), ("width", C.c_ushort), ("height", C.c_ushort),
+                ("precision", C.c_ubyte), ("restartInterval", C.c_ushort)]
+
+
+class _ScanInfo(C.Structure):
+    _fields_ = [("componentInfo", (C.c_uint8 * 3) * 4), ("maxH", C.c_ubyte), ("maxV", C.c_ubyte), ("n", C.c_ubyte)]
+
+
+def _walk(node, bits):
+    """src/hufftree.c:64-78 over the public tree"""
+    cur = node
+    for b in bits:
+        if b:
+            assert cur.hasRight
+            cur = cur.right.contents
+        else:
+            assert cur.hasLeft
+            cur = cur.left.contents
+        if cur.hasSymbol:
+            return cur.symbol
+    return None
+
+
+def test_jpeg_read_info_through_file_pointer(pkg, oracle, tmp_path):
+    """the reference's own entry point signature: FILE* in, jpeg_info/scan_info out, fp left at
+    the first entropy-coded byte (src/jpeg.c:55), trees walkable, jpeg_free safe twice."""
+    assert C.sizeof(_JpegInfo) == 1224 and C.sizeof(_ScanInfo) == 15
+    L = pkg.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.ftell.argtypes = [C.c_void_p]
+    libc.ftell.restype = C.c_long
+    libc.fclose.argtypes = [C.c_void_p]
+    L.jpeg_read_info.argtypes = [C.POINTER(_JpegInfo), C.POINTER(_ScanInfo), C.c_void_p]
+    L.jpeg_free.argtypes = [C.POINTER(_JpegInfo)]
+    L.jpeg_free.restype = None
+    for name in ("ex_birb", "ex_no_subsampling_lake", "syn_64x48_420_q85_dri4"):
+        data = golden_stream(name)
+        p = tmp_path / (name + ".jpg")
+        p.write_bytes(data)
+        fp = libc.fopen(str(p).encode(), b"rb")
+        ji, si = _JpegInfo(), _ScanInfo()
+        C.memset(C.byref(ji), 0xAB, C.sizeof(ji))      # src/test.c:21 passes an uninitialised struct
+        assert L.jpeg_read_info(C.byref(ji), C.byref(si), fp) == 0
+        rc, info = oracle.parse(data)
+        assert libc.ftell(fp) == info.scan_offset
+        assert (ji.width, ji.height, ji.precision, si.n) == (info.width, info.height, 8, info.ncomp)
+        assert (si.maxH, si.maxV) == (info.maxH, info.maxV)
+        assert ji.restartInterval == info.restart_interval
+        # first code of the DC table 0: walk the tree with its bits
+        t = info.huff[0][info.scomp[0].Td]
+        L0 = next(i + 1 for i in range(16) if t.counts[i])
+        assert _walk(ji.huffmanTables[0][info.scomp[0].Td], [0] * L0) == t.symbols[0]
+        L.jpeg_free(C.byref(ji))
+        L.jpeg_free(C.byref(ji))
+        libc.fclose(fp)
+    # failure path: jpeg_free after a rejected header must be safe (src/test.c:44-45)
+    p = tmp_path / "bad.jpg"
+    p.write_bytes(b"\xff\xd8\xff\xc0\x00\x05abc")
+    fp = libc.fopen(str(p).encode(), b"rb")
+    ji, si = _JpegInfo(), _ScanInfo()
+    C.memset(C.byref(ji), 0xAB, C.sizeof(ji))
+    assert L.jpeg_read_info(C.byref(ji), C.byref(si), fp) == -1
+    L.jpeg_free(C.byref(ji))
+    libc.fclose(fp)
+
+
+def test_rgb_to_ycbcr_host_matches_oracle(pkg, oracle):
+    """image_rgb_to_ycbcr (src/image.c:54-66) stays host C; same bytes as the oracle"""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    got = img.copy()
+    L = pkg.lib()
+    L.image_rgb_to_ycbcr.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    L.image_rgb_to_ycbcr.restype = None
+    L.image_rgb_to_ycbcr(got.ctypes.data, 53, 37)
+    assert np.array_equal(got, oracle.to_ycbcr(img))
+
+
+def _have_gpu(pkg):
+    return pkg.device_count() > 0
+
+
+def test_no_gpu_fails_loudly(pkg):
+    """the product has no CPU fallback: without a device every decode entry point errors"""
+    if _have_gpu(pkg):
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.JpegError, match="no HIP device"):
+        pkg.Decoder(0)
+    with pytest.raises(pkg.JpegError):
+        pkg.Batch([pkg.parse(golden_stream("syn_8x8_444_q85"))])
+    with pytest.raises(pkg.JpegError):
+        pkg.ycbcr_to_rgb(np.zeros((2, 2, 3), np.uint8))
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "streams", "ex_birb.jpg")], capture_output=True)
+    assert r.returncode != 0 and b"no HIP device" in r.stderr
+
+
+def test_cli_messages():
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout == "No path given.\n"                 # src/test.c:11
+    r = subprocess.run([exe, "/nonexistent.jpg"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.startswith("Could not open file: ")   # src/test.c:17
+    r = subprocess.run([exe, os.path.join(ROOT, "BASELINE.json")], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout == "Could not parse file.\n"          # src/test.c:24
