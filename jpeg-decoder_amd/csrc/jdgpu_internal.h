@@ -58,8 +58,15 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut *t, uint32_t v16) {
         for (int i = 0; i < 6; ++i) L += (v16 >= t->limit[i]) ? 1u : 0u;
         if (L > 16 || v16 < t->short_limit) {
             /* no code has this prefix: the reference's "Could not find next symbol in huffnode."
-             * (src/hufftree.c:69,72).  Speculative lanes must still make progress. */
-            s.len = 16; s.size = 0; s.run = 0; s.bad = 1;
+             * (src/hufftree.c:69,72).  Its bitwise walk stops at the first missing child, i.e.
+             * at the first bit where v16 exceeds the last assigned code (limit[5] - 1, canonical
+             * codes fill the code space from 0 upwards): that many bits are consumed, which is
+             * what decides between this failure and end-of-data.  Speculative lanes just need
+             * to make progress. */
+            uint32_t lim = t->limit[5];
+            uint32_t diff = (v16 ^ (lim - 1u)) & 0xFFFFu;
+            s.len = (lim == 0 || L <= 16) ? (lim == 0 ? 1u : 16u) : (uint32_t)__builtin_clz(diff | 1u) - 15u;
+            s.size = 0; s.run = 0; s.bad = 1;
         } else {
             uint32_t idx = (uint32_t)((int32_t)(v16 >> (16 - L)) + t->offset[L - JD_LUT_BITS - 1]) & 255u;
             uint32_t sym = t->symbols[idx];
