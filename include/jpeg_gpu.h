@@ -138,6 +138,11 @@ int  jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16,
 long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
                         uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap);
 
+/* the clean (unstuffed, interval-padded) stream and per-segment words the unstuff stage left on
+ * the device for image i; same format as jdgpu_host_unstuff.  Returns the segment count. */
+long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t clean_cap,
+                                uint32_t *seg_info, size_t seg_cap);
+
 /* ---- image.h on the device: src/image.c:39-51 over a host buffer (H2D, kernel, D2H) ------ */
 int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height);
 

@@ -49,6 +49,242 @@ static thread_local char g_err[512] = "";
 #define SEG_MASK 0x7FFu
 
 /* ============================================================================================
+ * unstuff: stuffed scan bytes -> clean, interval-padded stream (replaces src/bitstream.c:7-18)
+ *
+ * Reference semantics: a 0xFF read as data stays, the byte after it is dropped whatever it is.
+ * So a byte is a dropped "follower" iff the run of 0xFF bytes right before it has odd length.
+ * Restart extension: with a restart interval, an active 0xFF followed by 0xD0..0xD7 is a marker:
+ * both bytes go and the next interval starts; the marker after the last interval the frame
+ * geometry allows ends the data.
+ *
+ *   k_unstuff_count    per 4 KiB chunk: kept bytes, markers
+ *   k_unstuff_chunks   per image: exclusive scan of the chunk counts
+ *   k_unstuff_marks    per chunk: clean offset of every interval start (restart images only)
+ *   k_unstuff_layout   per image: segments per interval, per-segment words, tail padding
+ *   k_unstuff_scatter  per chunk: kept bytes to their padded position
+ * ========================================================================================== */
+
+struct RawLane {
+    uint32_t b[17];      /* the lane's 16 bytes + the one after */
+    uint32_t n;          /* how many of the 16 exist */
+    uint32_t d0;         /* 1 = the first byte is a dropped follower */
+};
+
+__device__ __forceinline__ RawLane raw_lane_load(const uint8_t *raw, uint32_t raw_len, uint32_t i0) {
+    RawLane r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t nx = 0;
+    r.n = i0 < raw_len ? min(16u, raw_len - i0) : 0u;
+    if (r.n) {
+        v = *reinterpret_cast<const uint4 *>(raw + i0);          /* raw regions are 16-B aligned, zero padded */
+        nx = (i0 + 16 < raw_len) ? raw[i0 + 16] : 0u;
+    }
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.b[i] = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+    r.b[16] = nx;
+    /* parity of the 0xFF run that ends right before i0 (bounded walk: >=4 consecutive 0xFF give
+     * 16 one-bits in the clean stream, which no Huffman table can decode, so the image fails
+     * either way and the parity of a longer run cannot matter) */
+    uint32_t run = 0;
+    if (r.n && i0 > 0 && raw[i0 - 1] == 0xFF) {
+        run = 1;
+        while (run < 1024u && run < i0 && raw[i0 - 1 - run] == 0xFF) ++run;
+    }
+    r.d0 = run & 1u;
+    return r;
+}
+
+/* classification of the lane's bytes: bit i of keep = byte i goes to the clean stream,
+ * bit i of mark = byte i is the 0xFF of a restart marker */
+__device__ __forceinline__ void raw_lane_classify(const RawLane &r, bool use_rst, uint32_t &keep, uint32_t &mark) {
+    keep = 0; mark = 0;
+    uint32_t d = r.d0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bool ex = (uint32_t)i < r.n;
+        uint32_t c = r.b[i];
+        bool ff = ex && !d && c == 0xFF;
+        /* b[i+1] past the end of the scan is zero padding, never 0xD0..0xD7 */
+        bool mk = ff && use_rst && r.b[i + 1] >= 0xD0 && r.b[i + 1] <= 0xD7;
+        bool kp = ex && !d && !mk;
+        keep |= (kp ? 1u : 0u) << i;
+        mark |= (mk ? 1u : 0u) << i;
+        d = ff ? 1u : 0u;
+    }
+}
+
+/* exclusive prefix sums of (a, b) over the 256 lanes of a work-group; totals in ta, tb */
+__device__ __forceinline__ void wg_exclusive_scan2(uint32_t a, uint32_t b, uint32_t *s_tmp /* [8] */,
+                                                   uint32_t &ea, uint32_t &eb, uint32_t &ta, uint32_t &tb) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t oa = __shfl_up(ia, d), ob = __shfl_up(ib, d);
+        if ((int)lane >= d) { ia += oa; ib += ob; }
+    }
+    if (lane == 63) { s_tmp[wave] = ia; s_tmp[4 + wave] = ib; }
+    __syncthreads();
+    uint32_t pa = 0, pb = 0;
+    ta = 0; tb = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < wave) { pa += s_tmp[w]; pb += s_tmp[4 + w]; }
+        ta += s_tmp[w]; tb += s_tmp[4 + w];
+    }
+    ea = pa + ia - a; eb = pb + ib - b;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_unstuff_count(const jd_image *__restrict__ imgs,
+                                                       const jd_raw_wg *__restrict__ wgs,
+                                                       const uint8_t *__restrict__ raw,
+                                                       uint2 *__restrict__ chunk_cnt) {
+    __shared__ uint32_t s_tmp[8];
+    const jd_raw_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    RawLane r = raw_lane_load(raw + im.raw_off, im.raw_len, wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+    uint32_t keep, mark;
+    raw_lane_classify(r, im.ri_blocks != 0, keep, mark);
+    uint32_t ea, eb, ta, tb;
+    wg_exclusive_scan2(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
+    if (threadIdx.x == 0) chunk_cnt[im.chunk_off + wg.chunk] = make_uint2(ta, tb);
+}
+
+/* one work-group per image: chunk_base = exclusive scan of chunk_cnt; U[0] = 0 and, when the
+ * stream holds fewer markers than the geometry allows, the end of the last interval */
+__global__ __launch_bounds__(256) void k_unstuff_chunks(const jd_image *__restrict__ imgs,
+                                                        const uint2 *__restrict__ chunk_cnt,
+                                                        uint2 *__restrict__ chunk_base,
+                                                        uint32_t *__restrict__ ivl_u) {
+    __shared__ uint32_t s_tmp[8];
+    const jd_image &im = imgs[blockIdx.x];
+    if (!im.ncomp) return;
+    uint32_t ca = 0, cb = 0;
+    for (uint32_t base = 0; base < im.n_chunks; base += 256) {
+        uint32_t c = base + threadIdx.x;
+        uint2 v = c < im.n_chunks ? chunk_cnt[im.chunk_off + c] : make_uint2(0, 0);
+        uint32_t ea, eb, ta, tb;
+        wg_exclusive_scan2(v.x, v.y, s_tmp, ea, eb, ta, tb);
+        if (c < im.n_chunks) chunk_base[im.chunk_off + c] = make_uint2(ca + ea, cb + eb);
+        ca += ta; cb += tb;
+    }
+    if (threadIdx.x == 0) {
+        ivl_u[im.u_off] = 0;
+        if (cb < im.n_intervals) ivl_u[im.u_off + cb + 1] = ca;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unstuff_marks(const jd_image *__restrict__ imgs,
+                                                       const jd_raw_wg *__restrict__ wgs,
+                                                       const uint8_t *__restrict__ raw,
+                                                       const uint2 *__restrict__ chunk_cnt,
+                                                       const uint2 *__restrict__ chunk_base,
+                                                       uint32_t *__restrict__ ivl_u) {
+    __shared__ uint32_t s_tmp[8];
+    const jd_raw_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    if (chunk_cnt[im.chunk_off + wg.chunk].y == 0) return; /* no marker in this chunk */
+    RawLane r = raw_lane_load(raw + im.raw_off, im.raw_len, wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+    uint32_t keep, mark;
+    raw_lane_classify(r, true, keep, mark);
+    uint32_t ea, eb, ta, tb;
+    wg_exclusive_scan2(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
+    const uint2 cb = chunk_base[im.chunk_off + wg.chunk];
+    uint32_t u = cb.x + ea, m = cb.y + eb;
+    while (mark) {
+        uint32_t i = __ffs(mark) - 1;
+        mark &= mark - 1;
+        uint32_t before = __popc(keep & ((1u << i) - 1u));
+        if (m < im.n_intervals) ivl_u[im.u_off + m + 1] = u + before; /* interval m+1 starts here */
+        ++m;
+    }
+}
+
+/* one work-group per image: interval lengths -> first segment of each interval, n_segs, the
+ * per-segment words and the 0xFF padding behind each interval */
+__global__ __launch_bounds__(256) void k_unstuff_layout(jd_image *__restrict__ imgs,
+                                                        const uint32_t *__restrict__ ivl_u,
+                                                        uint32_t *__restrict__ ivl_seg,
+                                                        uint32_t *__restrict__ seg_info,
+                                                        uint8_t *__restrict__ clean) {
+    __shared__ uint32_t s_tmp[8];
+    jd_image &im = imgs[blockIdx.x];
+    if (!im.ncomp) return;
+    const uint32_t nI = im.n_intervals;
+    const uint32_t *U = ivl_u + im.u_off;
+    uint32_t *S = ivl_seg + im.ivl_off;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nI; base += 256) {
+        uint32_t j = base + threadIdx.x, ns = 0;
+        if (j < nI) {
+            uint32_t a = U[j], b = U[j + 1];
+            /* intervals the stream never reaches (fewer markers than the geometry allows) get
+             * no segment; a reached but empty interval still gets one */
+            if (a != ~0u && b != ~0u && b >= a) ns = max(1u, (b - a + JD_SEG_BYTES - 1) / JD_SEG_BYTES);
+        }
+        uint32_t ea, eb, ta, tb;
+        wg_exclusive_scan2(ns, 0, s_tmp, ea, eb, ta, tb);
+        if (j < nI) S[j] = carry + ea;
+        carry += ta;
+    }
+    const uint32_t n_segs = min(carry, im.seg_cap);
+    if (threadIdx.x == 0) im.n_segs = n_segs;
+    __syncthreads(); /* S[] written above is read below by other lanes of this work-group */
+    for (uint32_t s = threadIdx.x; s < n_segs; s += 256) {
+        uint32_t lo = 0, hi = nI - 1; /* last interval whose first segment is <= s */
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (S[mid] <= s) lo = mid; else hi = mid - 1;
+        }
+        uint32_t a = U[lo], b = U[lo + 1];
+        uint32_t len = (a != ~0u && b != ~0u && b >= a) ? b - a : 0u;
+        uint32_t k = s - S[lo];
+        uint32_t bytes = len > k * JD_SEG_BYTES ? min(JD_SEG_BYTES, len - k * JD_SEG_BYTES) : 0u;
+        seg_info[im.seg_off + s] = (bytes * 8u) | (k == 0 ? JD_SEG_FIRST : 0u);
+        uint8_t *dst = clean + im.clean_off + (size_t)s * JD_SEG_BYTES;
+        for (uint32_t q = bytes; q < JD_SEG_BYTES; ++q) dst[q] = 0xFF;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restrict__ imgs,
+                                                         const jd_raw_wg *__restrict__ wgs,
+                                                         const uint8_t *__restrict__ raw,
+                                                         const uint2 *__restrict__ chunk_base,
+                                                         const uint32_t *__restrict__ ivl_u,
+                                                         const uint32_t *__restrict__ ivl_seg,
+                                                         uint8_t *__restrict__ clean) {
+    __shared__ uint32_t s_tmp[8];
+    const jd_raw_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    RawLane r = raw_lane_load(raw + im.raw_off, im.raw_len, wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+    uint32_t keep, mark;
+    raw_lane_classify(r, im.ri_blocks != 0, keep, mark);
+    uint32_t ea, eb, ta, tb;
+    wg_exclusive_scan2(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
+    const uint2 cb = chunk_base[im.chunk_off + wg.chunk];
+    uint32_t u = cb.x + ea, m = cb.y + eb; /* clean offset (unpadded) and interval of the next kept byte */
+    const uint32_t nI = im.n_intervals, seg_cap = im.seg_cap;
+    const uint32_t *U = ivl_u + im.u_off;
+    const uint32_t *S = ivl_seg + im.ivl_off;
+    uint8_t *dst = clean + im.clean_off;
+    uint32_t active = keep | mark;
+    int64_t delta = 0; /* padded position = u + delta within the interval */
+    bool have = false;
+    while (active) {
+        uint32_t i = __ffs(active) - 1;
+        active &= active - 1;
+        if (mark >> i & 1u) { ++m; have = false; continue; }
+        if (m >= nI) break; /* behind the marker that ends the data */
+        if (!have) { delta = (int64_t)S[m] * JD_SEG_BYTES - (int64_t)U[m]; have = true; }
+        int64_t pos = (int64_t)u + delta;
+        if (pos >= 0 && pos < (int64_t)seg_cap * JD_SEG_BYTES) dst[pos] = (uint8_t)r.b[i];
+        ++u;
+    }
+}
+
+/* ============================================================================================
  * Huffman: per-lane sequential decoder over one 1024-bit segment
  * ========================================================================================== */
 
@@ -693,6 +929,10 @@ struct jdgpu_batch {
     int16_t *d_coef;
     jd_huff_wg *d_hwg;
     jd_pix_wg *d_pwg;
+    jd_raw_wg *d_rwg;
+    uint2 *d_chunk_cnt, *d_chunk_base;
+    uint32_t *d_ivl_u, *d_ivl_seg;
+    bool any_rst;
     hipEvent_t ev[JDGPU_NSTAGES + 1];
     float ms[JDGPU_NSTAGES];
     std::vector<uint32_t> status;
@@ -758,6 +998,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_wg_exit[0]);
     hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt);
     hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
+    hipFree(b->d_rwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
     if (b->h_changed) hipHostFree(b->h_changed);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -772,11 +1013,12 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     if (rc) return rc;
     jdgpu_batch *b = new jdgpu_batch();
     memset(static_cast<void *>(&b->plan), 0, sizeof b->plan);
-    b->flags = flags | JDGPU_HOST_PREP; /* TODO(unstuff on GPU) */
+    b->flags = flags;
     b->stream = nullptr; b->h_changed = nullptr; b->retries = 0; b->timed = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_wg_exit[0] = b->d_wg_exit[1] = b->d_status = b->d_changed = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
+    b->d_rwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
     for (auto &e : b->ev) e = nullptr;
     TRY(jd_plan_build(descs, n, &b->plan, g_err, sizeof g_err));
     jd_plan &P = b->plan;
@@ -804,6 +1046,12 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
+    TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
+    TRY(dalloc(&b->d_chunk_cnt, (size_t)P.n_rwg));
+    TRY(dalloc(&b->d_chunk_base, (size_t)P.n_rwg));
+    TRY(dalloc(&b->d_ivl_u, (size_t)P.n_u));
+    TRY(dalloc(&b->d_ivl_seg, (size_t)P.n_intervals));
+    for (size_t i = 0; i < n; ++i) b->any_rst |= P.img[i].ncomp && P.img[i].ri_blocks != 0;
 
     if (b->flags & JDGPU_HOST_PREP) {
         jd_plan_unstuff_host(&P);
@@ -815,6 +1063,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemset(b->d_pix, 0, (size_t)P.pix_bytes + 256));
     HIPTRY(hipMemset(b->d_status, 0, (n ? n : 1) * 4));
     /* the host copies of the bulky arrays are not needed any more */
@@ -847,7 +1096,18 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
     HIPCHK(hipMemsetAsync(b->d_changed, 0, 64, st));
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
-    /* unstuff: TODO GPU stage; host prep already uploaded the clean stream */
+    if (!(b->flags & JDGPU_HOST_PREP) && P.n_rwg) {
+        HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
+        hipLaunchKernelGGL(k_unstuff_count, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_cnt);
+        hipLaunchKernelGGL(k_unstuff_chunks, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u);
+        if (b->any_rst)
+            hipLaunchKernelGGL(k_unstuff_marks, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_cnt,
+                               b->d_chunk_base, b->d_ivl_u);
+        hipLaunchKernelGGL(k_unstuff_layout, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_ivl_u, b->d_ivl_seg,
+                           b->d_seg_info, b->d_clean);
+        hipLaunchKernelGGL(k_unstuff_scatter, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_base,
+                           b->d_ivl_u, b->d_ivl_seg, b->d_clean);
+    }
     if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
     if (P.n_hwg) enqueue_huffman(b, true);
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
@@ -938,6 +1198,17 @@ extern "C" int jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *
     for (size_t k = 0; k < nb; ++k)
         for (int z = 0; z < 64; ++z) dst[k * 64 + z] = tmp[k * 64 + jd_zigzag_to_cm[z]];
     return JDGPU_OK;
+}
+
+extern "C" long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t clean_cap,
+                                           uint32_t *seg_info, size_t seg_cap) {
+    if (!b || i >= b->plan.n) return JDGPU_ERR_ARG;
+    jd_image im;
+    HIPCHK(hipMemcpy(&im, b->d_img + i, sizeof im, hipMemcpyDeviceToHost));
+    if ((size_t)im.n_segs > seg_cap || (size_t)im.n_segs * JD_SEG_BYTES > clean_cap) return JDGPU_ERR_ARG;
+    HIPCHK(hipMemcpy(clean, b->d_clean + im.clean_off, (size_t)im.n_segs * JD_SEG_BYTES, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(seg_info, b->d_seg_info + im.seg_off, (size_t)im.n_segs * 4, hipMemcpyDeviceToHost));
+    return (long)im.n_segs;
 }
 
 extern "C" int jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]) {

@@ -101,6 +101,10 @@ typedef struct {
     uint32_t ri_blocks;    /* data units per restart interval, 0 = no restart markers */
     uint32_t n_intervals;
     uint32_t ivl_off;      /* index of the image's first interval in the interval arrays */
+    uint32_t u_off;        /* index of its first entry in the interval-offset array (n_intervals+1 each) */
+    uint32_t chunk_off;    /* index of its first raw chunk in the per-chunk arrays */
+    uint32_t n_chunks;     /* raw chunks of JD_RAW_CHUNK bytes */
+    uint32_t pad2_;
     uint32_t lut_off;      /* index of the image's first jd_lut (JD_LUT_SLOTS each) */
     uint32_t mcus_x, mcus_y;
     uint16_t width, height;
@@ -119,6 +123,8 @@ typedef struct {
 /* work descriptors: one per work-group */
 typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* JD_WG_SEGS segments from seg0 */
 typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of an MCU row */
+typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */
+#define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
 
 #define JD_STRIP_PX 256u  /* pixel-kernel strip width */
 
@@ -135,6 +141,8 @@ typedef struct {
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
     jd_pix_wg *pwg;  uint32_t n_pwg;
+    jd_raw_wg *rwg;  uint32_t n_rwg;
+    uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;
     /* filled only by jd_prep_unstuff_host (JDGPU_HOST_PREP) */
     uint8_t *clean;          /* [clean_bytes] */

@@ -76,7 +76,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
 
     size_t raw = 0, clean = 0, pix = 0;
     uint64_t blk = 0;
-    uint32_t segs = 0, ivls = 0, nh = 0, np = 0;
+    uint32_t segs = 0, ivls = 0, nh = 0, np = 0, nr = 0, nu = 0;
     for (size_t i = 0; i < n; ++i) {
         const jdgpu_image_desc *d = &descs[i];
         jd_image *im = &P->img[i];
@@ -140,6 +140,9 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         im->seg_cap = (uint32_t)((d->scan_len + JD_SEG_BYTES - 1) / JD_SEG_BYTES) + im->n_intervals;
         raw += align_up(d->scan_len + 16, 16);
         clean += (size_t)im->seg_cap * JD_SEG_BYTES;
+        im->u_off = nu; im->chunk_off = nr;
+        im->n_chunks = (uint32_t)((d->scan_len + JD_RAW_CHUNK - 1) / JD_RAW_CHUNK);
+        nu += im->n_intervals + 1; nr += im->n_chunks;
         segs += im->seg_cap; ivls += im->n_intervals; blk += im->n_blocks;
         nh += (im->seg_cap + JD_WG_SEGS - 1) / JD_WG_SEGS;
         uint32_t strip = JD_STRIP_PX / (8u * maxH);
@@ -147,16 +150,18 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
     }
     P->raw_bytes = raw + 64; P->clean_bytes = clean + JD_SEG_BYTES * 2;
     P->n_segs_cap = segs; P->n_intervals = ivls; P->total_blocks = blk; P->pix_bytes = pix;
-    P->n_hwg = nh; P->n_pwg = np;
+    P->n_hwg = nh; P->n_pwg = np; P->n_rwg = nr; P->n_u = nu;
+    P->rwg = calloc(nr ? nr : 1, sizeof *P->rwg);
     P->raw = calloc(P->raw_bytes, 1);
     P->hwg = calloc(nh ? nh : 1, sizeof *P->hwg);
     P->pwg = calloc(np ? np : 1, sizeof *P->pwg);
-    if (!P->raw || !P->hwg || !P->pwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
-    nh = np = 0;
+    if (!P->raw || !P->hwg || !P->pwg || !P->rwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+    nh = np = nr = 0;
     for (size_t i = 0; i < n; ++i) {
         jd_image *im = &P->img[i];
         if (!im->ncomp) continue;
         memcpy(P->raw + im->raw_off, descs[i].scan, descs[i].scan_len);
+        for (uint32_t ch = 0; ch < im->n_chunks; ++ch) { P->rwg[nr].img = (uint32_t)i; P->rwg[nr].chunk = ch; ++nr; }
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
         uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
         for (uint32_t r = 0; r < im->mcus_y; ++r)
@@ -178,7 +183,10 @@ uint32_t jd_unstuff_image(const uint8_t *src, size_t raw_len, int use_rst, uint3
     for (;;) {
         int at_end = p >= raw_len;
         int marker = !at_end && use_rst && src[p] == 0xFF && p + 1 < raw_len &&
-                     src[p + 1] >= 0xD0 && src[p + 1] <= 0xD7 && ivl + 1 < n_intervals;
+                     src[p + 1] >= 0xD0 && src[p + 1] <= 0xD7;
+        /* a marker beyond the last interval the frame geometry allows ends the data: nothing
+         * after it can belong to the scan (the decoder stops at the next marker, T.81 E.2.4) */
+        if (marker && ivl + 1 >= n_intervals) at_end = 1;
         if (at_end || marker) {
             /* close the interval: pad to a segment boundary, emit its segment words */
             size_t len = o - ivl_start;
@@ -236,7 +244,7 @@ long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsig
 }
 
 void jd_plan_free(jd_plan *P) {
-    free(P->img); free(P->luts); free(P->raw); free(P->hwg); free(P->pwg);
+    free(P->img); free(P->luts); free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg);
     free(P->clean); free(P->seg_info);
     memset(P, 0, sizeof *P);
 }

@@ -202,3 +202,69 @@ def test_stage_timers(pkg, dec):
     b.decode()
     ms = b.stage_ms()
     assert ms["total"] > 0 and ms["pixel"] > 0 and ms["sync"] > 0
+
+
+def _host_unstuff(pkg, scan, use_rst, n_intervals):
+    import ctypes as C
+    L = pkg.lib()
+    cap = len(scan) // 128 + n_intervals + 2
+    clean = np.zeros(cap * 128, np.uint8)
+    seg = np.zeros(cap, np.uint32)
+    src = np.frombuffer(bytes(scan) + b"\0", np.uint8)
+    n = L.jdgpu_host_unstuff(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(scan), use_rst, n_intervals,
+                             clean.ctypes.data_as(C.POINTER(C.c_uint8)), clean.size,
+                             seg.ctypes.data_as(C.POINTER(C.c_uint32)), seg.size)
+    return clean[:n * 128], seg[:n]
+
+
+def _with_scan(pkg, base, scan):
+    d = pkg.parse(base)
+    buf = np.frombuffer(bytes(scan) + b"\0" * 16, np.uint8)
+    d.scan = buf.ctypes.data
+    d.scan_len = len(scan)
+    d._keep = buf
+    return d
+
+
+def test_unstuff_stage_equals_host_statement(pkg, dec, oracle):
+    """GPU unstuff (k_unstuff_*) == the host statement of src/bitstream.c:7-18 + restart split
+    (jdgpu_host_unstuff, itself checked against the reference byte reader on CPU), on every
+    fixture, on crafted 0xFF patterns and on marker counts that disagree with the geometry"""
+    files = [golden_stream(n) for n in all_golden_names()]
+    files.append(pkg.synth.make_jpeg(1920, 1080, seed=5, quality=85, subsamp=1, restart_mcus=120))
+    descs = [pkg.parse(f) for f in files]
+    base = golden_stream("syn_200x136_420_q50_dri13")   # 9 x 13 MCUs, 13 per interval -> 9 intervals
+    rng = np.random.default_rng(11)
+    crafted = [
+        bytes([0x12, 0xFF, 0x00, 0xFF, 0xD9]),
+        bytes([0xFF, 0xFF, 0xFF, 0x41, 0x07]),
+        bytes([0x01, 0xFF]),
+        bytes([1] * 3500) + b"\xff" * 999 + bytes([2, 3]),               # long 0xFF runs across a chunk edge
+        bytes([1] * 3501) + b"\xff" * 1000 + bytes([2, 3]),
+        bytes(rng.integers(0, 256, 20000, dtype=np.uint8)),               # random, many FF Dn
+        b"".join(bytes([i & 0x7F] * 300) + b"\xff" + bytes([0xD0 + (i & 7)]) for i in range(20)),  # surplus markers
+        b"".join(bytes([i & 0x7F] * 5) + b"\xff" + bytes([0xD0 + (i & 7)]) for i in range(4)),     # too few markers
+        bytes([7] * 4095) + b"\xff\xd3" + bytes([9] * 4097),            # marker straddling a 4 KiB chunk
+        bytes([7] * 4094) + b"\xff\x00\xff\xd3" + bytes([9] * 10),
+        b"",
+    ]
+    descs += [_with_scan(pkg, base, s) for s in crafted]
+    b = pkg.Batch(descs).decode()
+    for i, d in enumerate(descs):
+        scan = bytes(np.ctypeslib.as_array((__import__("ctypes").c_uint8 * d.scan_len).from_address(d.scan))) if d.scan_len else b""
+        mcux = -(-d.width // (8 * max(d.comp[c].H for c in range(3))))
+        mcuy = -(-d.height // (8 * max(d.comp[c].V for c in range(3))))
+        nI = -(-(mcux * mcuy) // d.restart_interval) if d.restart_interval else 1
+        want_clean, want_seg = _host_unstuff(pkg, scan, int(d.restart_interval != 0), nI)
+        got_clean, got_seg = b.segments(i)
+        assert np.array_equal(got_seg, want_seg), i
+        assert np.array_equal(got_clean, want_clean), i
+
+
+def test_host_prep_flag_gives_identical_output(pkg, dec):
+    files = [golden_stream(n) for n in all_golden_names()]
+    a = dec.decode(files)
+    h = dec.decode(files, flags=pkg.HOST_PREP)
+    for i in range(len(files)):
+        assert a.status(i) == h.status(i) == 0
+        assert np.array_equal(a.qcoef(i), h.qcoef(i)) and np.array_equal(a.rgb(i), h.rgb(i))
