@@ -132,9 +132,11 @@ int      jdgpu_batch_retries(const jdgpu_batch *b);
 /* decode the code at the top of the 16-bit window v16: 0 ok, -1 no such code, -2 bad table */
 int  jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, unsigned *len,
                            unsigned *run, unsigned *size);
-/* returns the number of 128-byte segments written (each restart interval padded with 0xFF to a
- * whole segment), -1 if the buffers are too small.  seg_info[i]: bit 31 = first segment of an
- * interval, low bits = valid bits in the segment. */
+/* bytes per bit-segment (one lane decodes one segment) */
+unsigned jdgpu_segment_bytes(void);
+/* returns the number of segments written (each restart interval padded with 0xFF to a whole
+ * segment, segments stored one after the other), -1 if the buffers are too small.
+ * seg_info[i]: bit 31 = first segment of an interval, low 16 bits = valid bits in the segment. */
 long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
                         uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap);
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "jdgpu_batch_read_pixels", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_ycbcr_to_rgb",
     "jdgpu_host_lut_lookup", "jdgpu_host_unstuff", "jdgpu_batch_debug_segments",
+    "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
     "image_print", "image_ycbcr_to_rgb", "image_rgb_to_ycbcr",
@@ -98,6 +99,7 @@ def lib():
                                         C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
     L.jdgpu_host_unstuff.restype = C.c_long
+    L.jdgpu_segment_bytes.restype = C.c_uint
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]
     L.jdgpu_batch_debug_segments.restype = C.c_long
     _lib = L
@@ -173,13 +175,14 @@ class Batch:
 
     def segments(self, i):
         """(clean stream bytes, per-segment words) the unstuff stage produced for image i"""
-        cap = self.descs[i].scan_len // 128 + 70000
-        clean = np.empty(cap * 128, np.uint8)
+        sb = self._L.jdgpu_segment_bytes()
+        cap = self.descs[i].scan_len // sb + 70000
+        clean = np.empty(cap * sb, np.uint8)
         seg = np.empty(cap, np.uint32)
         n = self._L.jdgpu_batch_debug_segments(self._h, i, clean.ctypes.data, clean.size, seg.ctypes.data, seg.size)
         if n < 0:
             raise _err(self._L, "jdgpu_batch_debug_segments", n)
-        return clean[:n * 128].copy(), seg[:n].copy()
+        return clean[:n * sb].copy(), seg[:n].copy()
 
     def stage_ms(self):
         ms = (C.c_float * len(STAGES))()
@@ -245,6 +248,10 @@ def ycbcr_to_rgb(img):
     if rc:
         raise _err(L, "jdgpu_ycbcr_to_rgb", rc)
     return out
+
+
+def segment_bytes():
+    return int(lib().jdgpu_segment_bytes())
 
 
 def device_count():

@@ -45,8 +45,17 @@ static thread_local char g_err[512] = "";
         }                                                                                         \
     } while (0)
 
-#define SEG_STRIDE (JD_SEG_WORDS + 1u) /* LDS words per staged segment: +1 breaks bank aliasing */
-#define SEG_MASK 0x7FFu
+#define SEG_MASK 0xFFFFu /* valid-bit count in a per-segment word */
+
+/* The clean stream is stored transposed in groups of 64 segments: word w of segment s lives at
+ * [(s / 64) * JD_SEG_WORDS + w][s % 64], so the 64 lanes of a wave -- one segment each, all
+ * roughly equally far into their segments -- read neighbouring dwords of the same cache lines. */
+__host__ __device__ __forceinline__ size_t clean_word_index(uint32_t seg, uint32_t w) {
+    return ((size_t)(seg >> 6) * JD_SEG_WORDS + w) * 64u + (seg & 63u);
+}
+__host__ __device__ __forceinline__ size_t clean_byte_addr(uint32_t seg, uint32_t o) {
+    return clean_word_index(seg, o >> 2) * 4u + (o & 3u);
+}
 
 /* ============================================================================================
  * unstuff: stuffed scan bytes -> clean, interval-padded stream (replaces src/bitstream.c:7-18)
@@ -243,8 +252,8 @@ __global__ __launch_bounds__(256) void k_unstuff_layout(jd_image *__restrict__ i
         uint32_t k = s - S[lo];
         uint32_t bytes = len > k * JD_SEG_BYTES ? min(JD_SEG_BYTES, len - k * JD_SEG_BYTES) : 0u;
         seg_info[im.seg_off + s] = (bytes * 8u) | (k == 0 ? JD_SEG_FIRST : 0u);
-        uint8_t *dst = clean + im.clean_off + (size_t)s * JD_SEG_BYTES;
-        for (uint32_t q = bytes; q < JD_SEG_BYTES; ++q) dst[q] = 0xFF;
+        uint8_t *dst = clean + im.clean_off;
+        for (uint32_t q = bytes; q < JD_SEG_BYTES; ++q) dst[clean_byte_addr(s, q)] = 0xFF;
     }
 }
 
@@ -279,34 +288,20 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
         if (m >= nI) break; /* behind the marker that ends the data */
         if (!have) { delta = (int64_t)S[m] * JD_SEG_BYTES - (int64_t)U[m]; have = true; }
         int64_t pos = (int64_t)u + delta;
-        if (pos >= 0 && pos < (int64_t)seg_cap * JD_SEG_BYTES) dst[pos] = (uint8_t)r.b[i];
+        if (pos >= 0 && pos < (int64_t)seg_cap * JD_SEG_BYTES)
+            dst[clean_byte_addr((uint32_t)(pos / JD_SEG_BYTES), (uint32_t)(pos % JD_SEG_BYTES))] = (uint8_t)r.b[i];
         ++u;
     }
 }
 
 /* ============================================================================================
- * Huffman: per-lane sequential decoder over one 1024-bit segment
+ * Huffman: per-lane sequential decoder over one segment of the clean stream
  * ========================================================================================== */
 
 struct SegTables {
     const jd_lut *lut;      /* LDS copy of the image's JD_LUT_SLOTS tables */
     const uint16_t *blk;    /* LDS: per data unit of the MCU: dc slot | ac slot << 4 | comp << 8 */
     uint32_t bpm;
-};
-
-/* word w (may run a little past 32) of the lane's staged segment */
-struct LdsWords {
-    const uint32_t *base; /* &s_words[lane * SEG_STRIDE] */
-    __device__ __forceinline__ uint32_t operator()(uint32_t w) const {
-        return __builtin_bswap32(base[w + (w >> 5)]);
-    }
-};
-/* the same words straight from the clean stream in global memory */
-struct GlobalWords {
-    const uint32_t *base;
-    __device__ __forceinline__ uint32_t operator()(uint32_t w) const {
-        return __builtin_bswap32(base[w]);
-    }
 };
 
 typedef jd_sym SymInfo;
@@ -317,6 +312,50 @@ __device__ __forceinline__ int extend(uint32_t bits, uint32_t size) {
     return (size == 0) ? 0 : ((bits >> (size - 1)) ? (int)bits : (int)bits - (int)(1u << size) + 1);
 }
 
+/*
+ * MSB-first bit reader over the lane's segment (and the first words of the next one: a symbol
+ * may straddle the boundary), replacing src/bitstream.c:28-45.  64-bit window, refilled one
+ * 32-bit word at a time from a three-deep register prefetch queue so that the global loads
+ * (L2 / Infinity Cache latency) are never on the symbol-to-symbol critical path.
+ */
+struct BitReader {
+    const uint32_t *own, *nxt; /* word 0 of this / the next segment; consecutive words are 64 dwords apart */
+    uint64_t buf;              /* next bits, left aligned */
+    uint32_t cnt;              /* valid bits in buf (>= 33 between symbols) */
+    uint32_t wi;               /* next word to prefetch */
+    uint32_t q1, q2, q3;       /* prefetched words wi-3, wi-2, wi-1 */
+
+    __device__ __forceinline__ uint32_t word(uint32_t w) const {
+        const uint32_t *p = w < JD_SEG_WORDS ? own + (size_t)w * 64u : nxt + (size_t)(w - JD_SEG_WORDS) * 64u;
+        return __builtin_bswap32(*p);
+    }
+    __device__ __forceinline__ void init(uint32_t p) {
+        uint32_t w = p >> 5;
+        buf = (((uint64_t)word(w) << 32) | word(w + 1)) << (p & 31u);
+        cnt = 64u - (p & 31u);
+        q1 = word(w + 2); q2 = word(w + 3); q3 = word(w + 4);
+        wi = w + 5;
+    }
+    __device__ __forceinline__ uint32_t top() const { return (uint32_t)(buf >> 32); }
+    __device__ __forceinline__ void consume(uint32_t n) { /* n <= 31 */
+        buf <<= n;
+        cnt -= n;
+        if (cnt <= 32u) {
+            buf |= (uint64_t)q1 << (32u - cnt);
+            cnt += 32u;
+            q1 = q2; q2 = q3; q3 = word(wi); ++wi;
+        }
+    }
+};
+
+__device__ __forceinline__ BitReader make_reader(const uint8_t *clean_img, uint32_t seg, uint32_t n_segs) {
+    BitReader r;
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(clean_img);
+    r.own = base + clean_word_index(seg, 0);
+    r.nxt = (seg + 1 < n_segs) ? base + clean_word_index(seg + 1, 0) : r.own;
+    return r;
+}
+
 struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
 
 /*
@@ -324,20 +363,14 @@ struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
  * segment's valid bits; report the exit state, the number of data units COMPLETED and the sum
  * of DC differences seen per component.
  */
-template <class Words>
-__device__ __forceinline__ LightResult decode_light(const Words &W, const SegTables &T, uint32_t in,
-                                                    uint32_t valid) {
+__device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables &T, uint32_t in, uint32_t valid) {
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
     uint32_t bad = 0;
     int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;
-    uint32_t wi = p >> 5;
-    uint64_t buf = ((uint64_t)W(wi) << 32) | W(wi + 1);
-    buf <<= (p & 31u);
-    uint32_t cnt = 64u - (p & 31u);
-    wi += 2;
+    R.init(p);
     uint32_t tb = T.blk[b];
     while (p < valid) {
-        uint32_t top = (uint32_t)(buf >> 32);
+        uint32_t top = R.top();
         bool isdc = (k == 0);
         const jd_lut *t = T.lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
         SymInfo s = lookup(t, top >> 16);
@@ -354,9 +387,7 @@ __device__ __forceinline__ LightResult decode_light(const Words &W, const SegTab
             k = (s.size == 0 && s.run != 15u) ? 64u : k + s.run + 1u;
         }
         p += tot;
-        buf <<= tot;
-        cnt -= tot;
-        if (cnt <= 32u) { buf |= (uint64_t)W(wi) << (32u - cnt); cnt += 32u; ++wi; }
+        R.consume(tot);
         if (k >= 64u) {
             k = 0; ++n;
             b = (b + 1 == T.bpm) ? 0 : b + 1;
@@ -370,19 +401,6 @@ __device__ __forceinline__ LightResult decode_light(const Words &W, const SegTab
     return r;
 }
 
-/* cooperative staging of JD_WG_SEGS+1 segments of the clean stream into padded LDS rows */
-__device__ __forceinline__ void stage_segments(uint32_t *s_words, const uint8_t *clean_img,
-                                               uint32_t seg0, uint32_t n_segs) {
-    const uint32_t nchunk = (JD_WG_SEGS + 1) * (JD_SEG_BYTES / 16);
-    for (uint32_t c = threadIdx.x; c < nchunk; c += blockDim.x) {
-        uint32_t s = c >> 3, q = c & 7u;
-        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (seg0 + s < n_segs) v = *reinterpret_cast<const uint4 *>(clean_img + (size_t)(seg0 + s) * JD_SEG_BYTES + q * 16);
-        uint32_t *d = s_words + s * SEG_STRIDE + q * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-}
-
 __device__ __forceinline__ void stage_tables(jd_lut *s_lut, uint16_t *s_blk, const jd_lut *g_lut, const jd_image &im) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
@@ -392,10 +410,20 @@ __device__ __forceinline__ void stage_tables(jd_lut *s_lut, uint16_t *s_blk, con
 }
 
 /*
- * k_huff_sync: speculative decode + intra-work-group stitching.
- * st_in/st_exit/cnt: per segment start state used, exit state reached, counts.
- * wg_exit[w]: exit state of the work-group's last segment (input of work-group w+1).
+ * k_huff_sync<RESYNC = false>: speculative decode + stitching inside a work-group of
+ * JD_WG_SEGS segments.  Every lane decodes its segment from the guess "bit 0, expecting DC,
+ * data unit 0" (exact for the first segment of a restart interval), then keeps re-decoding from
+ * its predecessor's exit state until no state in the work-group changes: JPEG Huffman streams
+ * self-synchronise, so a wrong start usually turns into the right exit within one segment.
+ *
+ * k_huff_sync<RESYNC = true>: stitch work-groups.  Lane 0 takes the exit state of the previous
+ * work-group's last segment (wg_exit_in, written by the previous launch); only lanes whose
+ * input changes re-decode.  *changed counts work-groups whose own last exit moved.
+ *
+ * st_in / st_exit / cnt: per segment the start state used, the exit state reached, and
+ * (data units completed, DC difference sums per component).
  */
+template <bool RESYNC>
 __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__restrict__ imgs,
                                                           const jd_lut *__restrict__ luts,
                                                           const uint8_t *__restrict__ clean,
@@ -404,68 +432,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
                                                           uint32_t *__restrict__ st_in,
                                                           uint32_t *__restrict__ st_exit,
                                                           int4 *__restrict__ cnt,
-                                                          uint32_t *__restrict__ wg_exit) {
-    __shared__ uint32_t s_words[(JD_WG_SEGS + 1) * SEG_STRIDE];
-    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
-    __shared__ uint16_t s_blk[16];
-    __shared__ uint32_t s_exit[JD_WG_SEGS];
-
-    const jd_huff_wg wg = wgs[blockIdx.x];
-    const jd_image &im = imgs[wg.img];
-    const uint32_t n_segs = im.n_segs;
-    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
-    if (wg.seg0 >= n_segs) {
-        if (lane == 0) wg_exit[blockIdx.x] = 0;
-        return;
-    }
-    stage_segments(s_words, clean + im.clean_off, wg.seg0, n_segs);
-    stage_tables(s_lut, s_blk, luts + im.lut_off, im);
-    __syncthreads();
-
-    const bool active = seg < n_segs;
-    const uint32_t si = active ? seg_info[im.seg_off + seg] : JD_SEG_FIRST;
-    const bool first = (si & JD_SEG_FIRST) != 0;
-    const uint32_t valid = si & SEG_MASK;
-    SegTables T{s_lut, s_blk, im.bpm};
-    LdsWords W{s_words + lane * SEG_STRIDE};
-
-    uint32_t in = 0; /* guess == true start state of an interval: bit 0, expecting DC, unit 0 */
-    LightResult r = decode_light(W, T, in, active ? valid : 0u);
-    for (uint32_t round = 0; round < JD_WG_SEGS; ++round) {
-        s_exit[lane] = r.exit_state & ~JD_ST_BAD;
-        __syncthreads();
-        uint32_t nin = (first || lane == 0) ? in : s_exit[lane - 1];
-        bool ch = active && nin != in;
-        if (ch) { in = nin; r = decode_light(W, T, in, valid); }
-        if (!__syncthreads_or(ch)) break;
-    }
-    if (active) {
-        st_in[im.seg_off + seg] = in;
-        st_exit[im.seg_off + seg] = r.exit_state;
-        cnt[im.seg_off + seg] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
-    }
-    uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
-    if (lane == last) wg_exit[blockIdx.x] = r.exit_state & ~JD_ST_BAD;
-}
-
-/*
- * k_huff_resync: stitch work-groups.  Lane 0 of every work-group takes the exit state of the
- * previous work-group's last segment; lanes whose input changes re-decode (straight from
- * global memory: only a lane or two per work-group does any work) until the change dies out.
- * Reads wg_exit_in (previous round), writes wg_exit_out; *changed counts work-groups whose
- * own last exit state moved (then another round is needed).
- */
-__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_resync(const jd_image *__restrict__ imgs,
-                                                            const jd_lut *__restrict__ luts,
-                                                            const uint8_t *__restrict__ clean,
-                                                            const uint32_t *__restrict__ seg_info,
-                                                            const jd_huff_wg *__restrict__ wgs,
-                                                            uint32_t *__restrict__ st_in,
-                                                            uint32_t *__restrict__ st_exit,
-                                                            int4 *__restrict__ cnt,
-                                                            const uint32_t *__restrict__ wg_exit_in,
-                                                            uint32_t *__restrict__ wg_exit_out,
-                                                            uint32_t *__restrict__ changed) {
+                                                          const uint32_t *__restrict__ wg_exit_in,
+                                                          uint32_t *__restrict__ wg_exit_out,
+                                                          uint32_t *__restrict__ changed) {
     __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
     __shared__ uint16_t s_blk[16];
     __shared__ uint32_t s_exit[JD_WG_SEGS];
@@ -479,29 +448,36 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_resync(const jd_image *__re
         return;
     }
     const bool active = seg < n_segs;
-    const uint32_t si = active ? seg_info[im.seg_off + seg] : JD_SEG_FIRST;
+    const uint32_t gs = im.seg_off + seg;
+    const uint32_t si = active ? seg_info[gs] : JD_SEG_FIRST;
     const bool first = (si & JD_SEG_FIRST) != 0;
     const uint32_t valid = si & SEG_MASK;
-    uint32_t in = active ? st_in[im.seg_off + seg] : 0u;
-    uint32_t ex = active ? st_exit[im.seg_off + seg] : 0u;
     const uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
 
-    /* work-group 0 of an image starts an interval; others chain to their predecessor */
-    uint32_t nin0 = (first || wg.seg0 == 0) ? in : wg_exit_in[blockIdx.x - 1];
-    bool ch = active && lane == 0 && nin0 != in;
-    if (!__syncthreads_or(ch)) {
-        if (lane == last) wg_exit_out[blockIdx.x] = ex & ~JD_ST_BAD;
-        return;
+    uint32_t in = 0; /* the guess == the true start state of a restart interval */
+    uint32_t ex0 = 0;
+    bool ch = active;
+    uint32_t nin = 0;
+    if (RESYNC) {
+        in = active ? st_in[gs] : 0u;
+        ex0 = active ? st_exit[gs] : 0u;
+        /* work-group 0 of an image starts an interval; the others chain to their predecessor */
+        nin = (first || wg.seg0 == 0 || lane != 0) ? in : wg_exit_in[blockIdx.x - 1];
+        ch = active && nin != in;
+        if (!__syncthreads_or(ch)) {
+            if (lane == last) wg_exit_out[blockIdx.x] = ex0 & ~JD_ST_BAD;
+            return;
+        }
     }
     stage_tables(s_lut, s_blk, luts + im.lut_off, im);
     __syncthreads();
     SegTables T{s_lut, s_blk, im.bpm};
-    GlobalWords W{reinterpret_cast<const uint32_t *>(clean + im.clean_off + (size_t)seg * JD_SEG_BYTES)};
-    LightResult r; r.exit_state = ex; r.n = 0; r.dc0 = r.dc1 = r.dc2 = 0;
+    BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
+
+    LightResult r; r.exit_state = ex0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
     bool dirty = false;
-    uint32_t nin = nin0;
-    for (uint32_t round = 0; round <= JD_WG_SEGS; ++round) {
-        if (ch) { in = nin; r = decode_light(W, T, in, valid); dirty = true; }
+    for (uint32_t round = 0; round <= JD_WG_SEGS + 1; ++round) {
+        if (ch) { in = nin; r = decode_light(R, T, in, valid); dirty = true; }
         s_exit[lane] = r.exit_state & ~JD_ST_BAD;
         __syncthreads();
         nin = (first || lane == 0) ? in : s_exit[lane - 1];
@@ -509,13 +485,13 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_resync(const jd_image *__re
         if (!__syncthreads_or(ch)) break;
     }
     if (dirty) {
-        st_in[im.seg_off + seg] = in;
-        st_exit[im.seg_off + seg] = r.exit_state;
-        cnt[im.seg_off + seg] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+        st_in[gs] = in;
+        st_exit[gs] = r.exit_state;
+        cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
     }
     if (lane == last) {
         wg_exit_out[blockIdx.x] = r.exit_state & ~JD_ST_BAD;
-        if (dirty && ((r.exit_state ^ ex) & ~JD_ST_BAD)) atomicAdd(changed, 1u);
+        if (RESYNC && dirty && ((r.exit_state ^ ex0) & ~JD_ST_BAD)) atomicAdd(changed, 1u);
     }
 }
 
@@ -598,6 +574,22 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
 
 __constant__ uint8_t c_zz_cm[64];
 
+/*
+ * k_huff_write: one lane per segment again, now from the true start state.  A data unit is
+ * written entirely by the lane in whose segment it STARTS (that lane runs on into the next
+ * segment to finish its last unit; a lane that starts in the middle of a unit decodes the rest
+ * of it without storing).  Coefficients are assembled in a 128-byte LDS buffer per lane; after
+ * every symbol step the wave flushes the units that were completed in that step together:
+ * 8 lanes per unit write its 128-byte line with one 16-byte store each (full, coalesced lines
+ * instead of ~12 scattered 2-byte stores per unit) and clear the buffer for the next unit.
+ */
+#define WBUF_BYTES 128u
+__device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
+    /* 16-byte chunks rotated by the lane number: both the lanes' scattered stores and the
+     * 8-lanes-per-unit flush spread over the LDS banks */
+    return lane * WBUF_BYTES + ((((idx >> 3) + lane) & 7u) << 4) + ((idx & 7u) << 1);
+}
+
 __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
                                                            const uint8_t *__restrict__ clean,
@@ -609,8 +601,11 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
                                                            const int4 *__restrict__ start_dc,
                                                            int16_t *__restrict__ coef,
                                                            uint32_t *__restrict__ status) {
-    __shared__ uint32_t s_words[(JD_WG_SEGS + 1) * SEG_STRIDE];
+    static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
     __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[JD_WG_SEGS * WBUF_BYTES];
+    __shared__ uint32_t s_qblk[JD_WG_SEGS];   /* per wave: global unit index of the r-th finished unit */
+    __shared__ uint8_t s_qlane[JD_WG_SEGS];   /* per wave: lane (within the work-group) that holds it */
     __shared__ uint16_t s_blk[16];
     __shared__ uint8_t s_cm[64];
 
@@ -619,29 +614,35 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
     const uint32_t n_segs = im.n_segs;
     if (wg.seg0 >= n_segs) return;
     const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
-    stage_segments(s_words, clean + im.clean_off, wg.seg0, n_segs);
+    const uint32_t wlane = lane & 63u, wbase = lane & ~63u;
     stage_tables(s_lut, s_blk, luts + im.lut_off, im);
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_buf + lane * WBUF_BYTES);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
-    if (seg >= n_segs) return;
+    bool active = seg < n_segs;
+    if (!__any(active)) return; /* whole wave beyond the image: no further work-group barrier below */
 
-    const uint32_t gs = im.seg_off + seg;
+    const uint32_t gs = im.seg_off + (active ? seg : wg.seg0);
     const uint32_t si = seg_info[gs];
     const bool first = (si & JD_SEG_FIRST) != 0;
     const uint32_t valid = si & SEG_MASK;
-    /* bits this lane may consume: its own segment plus, when that is full and the interval
-     * goes on, the next one (a symbol may straddle the boundary) */
+    /* bits this lane may consume: its own segment plus the next one of the same interval */
     uint32_t avail = valid;
     bool is_last = true; /* last segment of its restart interval */
-    if (seg + 1 < n_segs) {
+    if (active && seg + 1 < n_segs) {
         uint32_t sn = seg_info[gs + 1];
         if (!(sn & JD_SEG_FIRST)) { is_last = false; avail += sn & SEG_MASK; }
     }
     const uint32_t in = st_in[gs];
     uint32_t flags = 0;
-    /* chain check: the state this segment starts from must be the one its predecessor ended in */
-    if (!first && seg > 0 && ((st_exit[gs - 1] ^ in) & ~JD_ST_BAD)) flags |= JDGPU_IMG_UNSYNCED;
-    if (first && in != 0) flags |= JDGPU_IMG_UNSYNCED;
+    /* chain check: the state this segment starts from must be the one its predecessor ended in
+     * (it is not when a correction crossed a whole work-group: the host then stitches again) */
+    if (active && !first && seg > 0 && ((st_exit[gs - 1] ^ in) & ~JD_ST_BAD)) flags |= JDGPU_IMG_UNSYNCED;
+    if (active && first && in != 0) flags |= JDGPU_IMG_UNSYNCED;
 
     const int2 sb = start_blk[gs];
     const int4 sd = start_dc[gs];
@@ -650,57 +651,79 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
     int pr0 = sd.x, pr1 = sd.y, pr2 = sd.z;
 
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
-    LdsWords W{s_words + lane * SEG_STRIDE};
-    uint32_t wi = p >> 5;
-    uint64_t buf = ((uint64_t)W(wi) << 32) | W(wi + 1);
-    buf <<= (p & 31u);
-    uint32_t cnt = 64u - (p & 31u);
-    wi += 2;
+    BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
+    R.init(p);
     uint32_t tb = s_blk[b];
-    int16_t *cb = coef + ((size_t)im.blk_off + (size_t)B) * 64;
+    bool own = (k == 0); /* does this lane own the data unit it is in? */
+    int16_t *const cbase = coef + (size_t)im.blk_off * 64;
 
-    while (p < valid && B < limit) {
-        uint32_t top = (uint32_t)(buf >> 32);
-        bool isdc = (k == 0);
-        const jd_lut *t = s_lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
-        SymInfo s = lookup(t, top >> 16);
-        uint32_t tot = s.len + s.size;
-        if (p + tot > avail) { flags |= JDGPU_IMG_EOF; break; }   /* src/bitstream.c:17 */
-        if (s.bad) { flags |= JDGPU_IMG_NOSYMBOL; break; }        /* src/hufftree.c:69,72 */
-        uint32_t mag = s.size ? ((top << s.len) >> (32u - s.size)) : 0u;
-        int val = extend(mag, s.size);
-        if (isdc) {
-            uint32_t c = tb >> 8;
-            int pv;
-            if (c == 0) { pr0 += val; pv = pr0; } else if (c == 1) { pr1 += val; pv = pr1; } else { pr2 += val; pv = pr2; }
-            cb[0] = (int16_t)pv;   /* src/decoding.c:44-46 (quantised: the multiply is in k_pixel) */
-            k = 1;
-        } else {
-            uint32_t kk = k + s.run;
-            if (s.size == 0) {
-                k = (s.run == 15u) ? kk + 1u : 64u;
-            } else {
-                if (kk < 64u) cb[s_cm[kk]] = (int16_t)val;  /* src/decoding.c:65 */
-                k = kk + 1u;
+    /* a unit is decoded while it STARTED before the end of the segment */
+    active = active && (k != 0 || p < valid) && B < limit;
+    while (__any(active)) {
+        bool finished = false; /* an OWNED unit was completed in this step */
+        int fB = 0;            /* ... and this is its index */
+        if (active) {
+            uint32_t top = R.top();
+            bool isdc = (k == 0);
+            const jd_lut *t = s_lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
+            SymInfo s = lookup(t, top >> 16);
+            uint32_t tot = s.len + s.size;
+            if (p + tot > avail) { flags |= JDGPU_IMG_EOF; active = false; }        /* src/bitstream.c:17 */
+            else if (s.bad) { flags |= JDGPU_IMG_NOSYMBOL; active = false; }        /* src/hufftree.c:69,72 */
+            else {
+                uint32_t mag = s.size ? ((top << s.len) >> (32u - s.size)) : 0u;
+                int val = extend(mag, s.size);
+                uint32_t kk;
+                bool store;
+                if (isdc) {
+                    uint32_t c = tb >> 8;
+                    if (c == 0) { pr0 += val; val = pr0; } else if (c == 1) { pr1 += val; val = pr1; } else { pr2 += val; val = pr2; }
+                    kk = 0; store = true;          /* src/decoding.c:44-46 (quantised; the multiply is in k_pixel) */
+                    k = 1;
+                } else {
+                    kk = k + s.run;
+                    store = own && s.size != 0 && kk < 64u;   /* src/decoding.c:65 */
+                    k = (s.size == 0 && s.run != 15u) ? 64u : kk + 1u;
+                }
+                if (store) *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
+                p += tot;
+                R.consume(tot);
+                if (k >= 64u) {
+                    finished = own; fB = B;
+                    k = 0; own = true; ++B;
+                    b = (b + 1 == im.bpm) ? 0 : b + 1;
+                    tb = s_blk[b];
+                }
             }
         }
-        p += tot;
-        buf <<= tot;
-        cnt -= tot;
-        if (cnt <= 32u) { buf |= (uint64_t)W(wi) << (32u - cnt); cnt += 32u; ++wi; }
-        if (k >= 64u) {
-            k = 0; ++B; cb += 64;
-            b = (b + 1 == im.bpm) ? 0 : b + 1;
-            tb = s_blk[b];
+        /* ---- flush the units completed in this step (wave-synchronous) ---- */
+        uint64_t fm = __ballot(finished);
+        if (fm) {
+            if (finished) {
+                uint32_t r = __popcll(fm & ((1ull << wlane) - 1ull));
+                s_qlane[wbase + r] = (uint8_t)wlane;
+                s_qblk[wbase + r] = (uint32_t)fB;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t nf = __popcll(fm), sub = wlane & 7u;
+            for (uint32_t g = wlane >> 3; g < nf; g += 8) {
+                uint32_t src = wbase + s_qlane[wbase + g];
+                uint32_t blk = s_qblk[wbase + g];
+                uint4 *lp = reinterpret_cast<uint4 *>(s_buf + src * WBUF_BYTES + (((sub + src) & 7u) << 4));
+                uint4 v = *lp;
+                *lp = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(cbase + (size_t)blk * 64 + sub * 8) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-    }
-    /* the light pass must have seen exactly this: same exit state when the segment ran to its end */
-    if (!(flags & (JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) && B < limit && !is_last) {
-        uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
-        if ((JD_ST_PACK(ovs, k, b) ^ st_exit[gs]) & ~JD_ST_BAD) flags |= JDGPU_IMG_UNSYNCED;
+        active = active && (k != 0 || p < valid) && B < limit;
     }
     /* data ended before the interval's data units did */
-    if (!flags && B < limit && is_last) flags |= JDGPU_IMG_EOF;
+    if (!flags && seg < n_segs && B < limit && is_last) flags |= JDGPU_IMG_EOF;
     if (flags) atomicOr(&status[wg.img], flags);
 }
 
@@ -1075,12 +1098,13 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     jd_plan &P = b->plan;
     if (first_pass) {
-        hipLaunchKernelGGL(k_huff_sync, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
-                           b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[0]);
+        hipLaunchKernelGGL(k_huff_sync<false>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
+                           b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[1], b->d_wg_exit[0],
+                           b->d_changed);
     }
     /* one stitching round across work-groups (more only if k_huff_write reports UNSYNCED) */
     int src = first_pass ? 0 : (b->retries & 1);
-    hipLaunchKernelGGL(k_huff_resync, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
+    hipLaunchKernelGGL(k_huff_sync<true>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
                        b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[src],
                        b->d_wg_exit[src ^ 1], b->d_changed);
     return JDGPU_OK;
@@ -1113,7 +1137,6 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
-    HIPCHK(hipMemsetAsync(b->d_coef, 0, (size_t)P.total_blocks * 128, st));
     if (P.n_hwg)
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
@@ -1148,7 +1171,6 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, s));
         enqueue_huffman(b, false);
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
-        HIPCHK(hipMemsetAsync(b->d_coef, 0, (size_t)P.total_blocks * 128, s));
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         if (b->flags & JDGPU_OUT_YCBCR)
@@ -1206,7 +1228,13 @@ extern "C" long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *cl
     jd_image im;
     HIPCHK(hipMemcpy(&im, b->d_img + i, sizeof im, hipMemcpyDeviceToHost));
     if ((size_t)im.n_segs > seg_cap || (size_t)im.n_segs * JD_SEG_BYTES > clean_cap) return JDGPU_ERR_ARG;
-    HIPCHK(hipMemcpy(clean, b->d_clean + im.clean_off, (size_t)im.n_segs * JD_SEG_BYTES, hipMemcpyDeviceToHost));
+    {
+        size_t groups = ((size_t)im.n_segs + 63) / 64, bytes = groups * 64 * JD_SEG_BYTES;
+        std::vector<uint8_t> t(bytes ? bytes : 1);
+        HIPCHK(hipMemcpy(t.data(), b->d_clean + im.clean_off, bytes, hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < im.n_segs; ++s)
+            for (uint32_t o = 0; o < JD_SEG_BYTES; ++o) clean[(size_t)s * JD_SEG_BYTES + o] = t[clean_byte_addr(s, o)];
+    }
     HIPCHK(hipMemcpy(seg_info, b->d_seg_info + im.seg_off, (size_t)im.n_segs * 4, hipMemcpyDeviceToHost));
     return (long)im.n_segs;
 }

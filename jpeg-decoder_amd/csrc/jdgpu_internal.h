@@ -18,9 +18,11 @@ extern "C" {
  * The unstuffed ("clean") entropy-coded stream of an image is laid out restart interval after
  * restart interval, each padded with 0xFF to a whole number of segments, so that every
  * interval starts a segment with a known decoder state.  One lane decodes one segment. */
-#define JD_SEG_WORDS   32u                    /* 32-bit words per segment */
-#define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 128 B  */
-#define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 1024 b */
+#ifndef JD_SEG_WORDS
+#define JD_SEG_WORDS   128u                   /* 32-bit words per segment */
+#endif
+#define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 512 B  */
+#define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 4096 b */
 #define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group */
 #define JD_MAX_BPM     12u                    /* data units per MCU: 3 components of at most 2x2 */
 #define JD_LUT_BITS    10u                    /* primary Huffman lookup width */
@@ -79,7 +81,7 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut *t, uint32_t v16) {
 
 /* per-segment word written by the unstuff stage */
 #define JD_SEG_FIRST 0x80000000u              /* first segment of a restart interval */
-/* low bits: number of valid bits in the segment (0..1024) */
+/* low 16 bits: number of valid bits in the segment (0..JD_SEG_BITS) */
 
 /* decoder state at a segment boundary, packed */
 /* bits 5:0 overshoot into the next segment, 12:6 zigzag index k (0 = expecting DC),

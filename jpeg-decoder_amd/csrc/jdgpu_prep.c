@@ -139,7 +139,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         im->raw_len = (uint32_t)d->scan_len;
         im->seg_cap = (uint32_t)((d->scan_len + JD_SEG_BYTES - 1) / JD_SEG_BYTES) + im->n_intervals;
         raw += align_up(d->scan_len + 16, 16);
-        clean += (size_t)im->seg_cap * JD_SEG_BYTES;
+        clean += (size_t)((im->seg_cap + 63) / 64) * 64 * JD_SEG_BYTES; /* whole 64-segment groups */
         im->u_off = nu; im->chunk_off = nr;
         im->n_chunks = (uint32_t)((d->scan_len + JD_RAW_CHUNK - 1) / JD_RAW_CHUNK);
         nu += im->n_intervals + 1; nr += im->n_chunks;
@@ -220,8 +220,15 @@ void jd_plan_unstuff_host(jd_plan *P) {
     for (size_t i = 0; i < P->n; ++i) {
         jd_image *im = &P->img[i];
         if (!im->ncomp) continue;
+        /* unstuff linearly, then store in the device layout: 64-segment groups, word-transposed */
+        uint8_t *lin = malloc((size_t)im->seg_cap * JD_SEG_BYTES);
         im->n_segs = jd_unstuff_image(P->raw + im->raw_off, im->raw_len, im->ri_blocks != 0, im->n_intervals,
-                                      P->clean + im->clean_off, P->seg_info + im->seg_off);
+                                      lin, P->seg_info + im->seg_off);
+        uint8_t *dst = P->clean + im->clean_off;
+        for (uint32_t s = 0; s < im->n_segs; ++s)
+            for (uint32_t o = 0; o < JD_SEG_BYTES; ++o)
+                dst[(((size_t)(s >> 6) * JD_SEG_WORDS + (o >> 2)) * 64u + (s & 63u)) * 4u + (o & 3u)] = lin[(size_t)s * JD_SEG_BYTES + o];
+        free(lin);
     }
 }
 
@@ -235,6 +242,8 @@ int jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, 
     *len = s.len; *run = s.run; *size = s.size;
     return s.bad ? -1 : 0;
 }
+
+unsigned jdgpu_segment_bytes(void) { return JD_SEG_BYTES; }
 
 long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
                         uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap) {

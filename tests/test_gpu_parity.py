@@ -207,14 +207,15 @@ def test_stage_timers(pkg, dec):
 def _host_unstuff(pkg, scan, use_rst, n_intervals):
     import ctypes as C
     L = pkg.lib()
-    cap = len(scan) // 128 + n_intervals + 2
-    clean = np.zeros(cap * 128, np.uint8)
+    SB = pkg.segment_bytes()
+    cap = len(scan) // SB + n_intervals + 2
+    clean = np.zeros(cap * SB, np.uint8)
     seg = np.zeros(cap, np.uint32)
     src = np.frombuffer(bytes(scan) + b"\0", np.uint8)
     n = L.jdgpu_host_unstuff(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(scan), use_rst, n_intervals,
                              clean.ctypes.data_as(C.POINTER(C.c_uint8)), clean.size,
                              seg.ctypes.data_as(C.POINTER(C.c_uint32)), seg.size)
-    return clean[:n * 128], seg[:n]
+    return clean[:n * SB], seg[:n]
 
 
 def _with_scan(pkg, base, scan):

@@ -156,15 +156,16 @@ def _ref_reader_bytes(scan):
 
 def _unstuff(pkg, scan, use_rst=0, n_intervals=1):
     L = pkg.lib()
-    cap = len(scan) // 128 + n_intervals + 2
-    clean = np.zeros(cap * 128, np.uint8)
+    SB = pkg.segment_bytes()
+    cap = len(scan) // SB + n_intervals + 2
+    clean = np.zeros(cap * SB, np.uint8)
     seg = np.zeros(cap, np.uint32)
     src = np.frombuffer(bytes(scan) + b"\0", np.uint8)
     n = L.jdgpu_host_unstuff(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(scan), use_rst, n_intervals,
                              clean.ctypes.data_as(C.POINTER(C.c_uint8)), clean.size,
                              seg.ctypes.data_as(C.POINTER(C.c_uint32)), seg.size)
     assert n >= 1
-    return clean[:n * 128], seg[:n]
+    return clean[:n * SB], seg[:n]
 
 
 def test_unstuff_matches_reference_reader(pkg, oracle):
@@ -174,7 +175,7 @@ def test_unstuff_matches_reference_reader(pkg, oracle):
         scan = data[off:]
         clean, seg = _unstuff(pkg, scan)
         want = _ref_reader_bytes(scan)
-        nbits = int((seg & 0x7FF).sum())
+        nbits = int((seg & 0xFFFF).sum())
         assert nbits == 8 * len(want)
         assert bytes(clean[:len(want)]) == want
         assert np.all(clean[len(want):] == 0xFF)           # padding
@@ -184,30 +185,31 @@ def test_unstuff_matches_reference_reader(pkg, oracle):
 def test_unstuff_tail_and_ff_runs(pkg):
     # birb.jpg ends "... FF 00 FF D9": the stuffed byte is the last data byte
     clean, seg = _unstuff(pkg, bytes([0x12, 0xFF, 0x00, 0xFF, 0xD9]))
-    assert bytes(clean[:3]) == bytes([0x12, 0xFF, 0xFF]) and (seg[0] & 0x7FF) == 24
+    assert bytes(clean[:3]) == bytes([0x12, 0xFF, 0xFF]) and (seg[0] & 0xFFFF) == 24
     # FF FF FF 41: first FF data, second dropped, third data, 0x41 dropped
     clean, seg = _unstuff(pkg, bytes([0xFF, 0xFF, 0xFF, 0x41, 0x07]))
-    assert bytes(clean[:3]) == bytes([0xFF, 0xFF, 0x07]) and (seg[0] & 0x7FF) == 24
+    assert bytes(clean[:3]) == bytes([0xFF, 0xFF, 0x07]) and (seg[0] & 0xFFFF) == 24
     # trailing lone FF
     clean, seg = _unstuff(pkg, bytes([0x01, 0xFF]))
-    assert bytes(clean[:2]) == bytes([0x01, 0xFF]) and (seg[0] & 0x7FF) == 16
+    assert bytes(clean[:2]) == bytes([0x01, 0xFF]) and (seg[0] & 0xFFFF) == 16
 
 
 def test_unstuff_restart_split(pkg):
-    a, b, c = bytes(range(1, 200)), bytes([0x55, 0xFF, 0x00, 0x66]), b""
+    SB = pkg.segment_bytes()
+    a, b, c = bytes(i % 251 + 1 for i in range(SB + 71)), bytes([0x55, 0xFF, 0x00, 0x66]), b""
     scan = a + b"\xff\xd0" + b + b"\xff\xd1" + c + b"\xff\xd2" + bytes([9, 9])
     clean, seg = _unstuff(pkg, scan, use_rst=1, n_intervals=4)
     firsts = np.nonzero(seg >> 31)[0]
     assert list(firsts) == [0, 2, 3, 4] and len(seg) == 5
-    assert list(seg & 0x7FF) == [1024, (199 - 128) * 8, 3 * 8, 0, 16]
-    assert bytes(clean[:199]) == a and bytes(clean[256:259]) == bytes([0x55, 0xFF, 0x66])
-    assert bytes(clean[512:514]) == bytes([9, 9])
+    assert list(seg & 0xFFFF) == [SB * 8, 71 * 8, 3 * 8, 0, 16]
+    assert bytes(clean[:len(a)]) == a and bytes(clean[2 * SB:2 * SB + 3]) == bytes([0x55, 0xFF, 0x66])
+    assert bytes(clean[4 * SB:4 * SB + 2]) == bytes([9, 9])
     # without a restart interval FF D0 is "data FF + dropped byte" like any other (src/bitstream.c:11-14)
     clean2, seg2 = _unstuff(pkg, scan, use_rst=0, n_intervals=1)
-    assert bytes(clean2[:int((seg2 & 0x7FF).sum()) // 8]) == _ref_reader_bytes(scan)
-    # more markers than intervals: the surplus is treated as data
+    assert bytes(clean2[:int((seg2 & 0xFFFF).sum()) // 8]) == _ref_reader_bytes(scan)
+    # more markers than intervals: the marker after the last interval ends the data
     clean3, seg3 = _unstuff(pkg, scan, use_rst=1, n_intervals=2)
-    assert int((seg3 >> 31).sum()) == 2
+    assert int((seg3 >> 31).sum()) == 2 and int((seg3 & 0xFFFF).sum()) == (len(a) + 3) * 8
 
 
 class _HuffNode(C.Structure):
