@@ -741,50 +741,57 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
 #define T7 0.195090
 
 /* 8-point inverse transform with the reference's table, even/odd split:
- * out[x] = sum_u in[u] * T[u][x];  T[u][7-x] = (-1)^u T[u][x] */
+ * out[x] = S * sum_u in[u] * T[u][x];  T[u][7-x] = (-1)^u T[u][x].  S is a power of two, so
+ * scaling the constants is exact and commutes with every rounding (S = 1/4 folds the
+ * reference's final "sum / 4", src/decoding.c:83, into the second pass). */
+template <int QUARTER>
 __device__ __forceinline__ void idct8(const double in[8], double out[8]) {
-    double e0 = in[0] * T0, e4 = in[4] * T0;
-    double a0 = e0 + e4, a1 = e0 - e4;                       /* u = 0, 4 */
-    double b0 = fma(in[2], T2, in[6] * T6);                  /* u = 2, 6 at x = 0 */
-    double b1 = fma(in[2], T6, -(in[6] * T2));               /* at x = 1 */
+    constexpr double S = QUARTER ? 0.25 : 1.0;
+    double e0 = in[0] * (T0 * S), e4 = in[4] * (T0 * S);
+    double a0 = e0 + e4, a1 = e0 - e4;                             /* u = 0, 4 */
+    double b0 = fma(in[2], T2 * S, in[6] * (T6 * S));              /* u = 2, 6 at x = 0 */
+    double b1 = fma(in[2], T6 * S, -(in[6] * (T2 * S)));           /* at x = 1 */
     double E0 = a0 + b0, E3 = a0 - b0, E1 = a1 + b1, E2 = a1 - b1;
-    double O0 = fma(in[1], T1, fma(in[3], T3, fma(in[5], T5, in[7] * T7)));
-    double O1 = fma(in[1], T3, fma(in[3], -T7, fma(in[5], -T1, in[7] * -T5)));
-    double O2 = fma(in[1], T5, fma(in[3], -T1, fma(in[5], T7, in[7] * T3)));
-    double O3 = fma(in[1], T7, fma(in[3], -T5, fma(in[5], T3, in[7] * -T1)));
+    double O0 = fma(in[1], T1 * S, fma(in[3], T3 * S, fma(in[5], T5 * S, in[7] * (T7 * S))));
+    double O1 = fma(in[1], T3 * S, fma(in[3], -T7 * S, fma(in[5], -T1 * S, in[7] * (-T5 * S))));
+    double O2 = fma(in[1], T5 * S, fma(in[3], -T1 * S, fma(in[5], T7 * S, in[7] * (T3 * S))));
+    double O3 = fma(in[1], T7 * S, fma(in[3], -T5 * S, fma(in[5], T3 * S, in[7] * (-T1 * S))));
     out[0] = E0 + O0; out[7] = E0 - O0;
     out[1] = E1 + O1; out[6] = E1 - O1;
     out[2] = E2 + O2; out[5] = E2 - O2;
     out[3] = E3 + O3; out[4] = E3 - O3;
 }
 
-/* src/decoding.c:99: clamp(lround(v) + 128, 0, 255); lround = half away from zero */
+/* src/decoding.c:99: clamp(lround(v) + 128, 0, 255).  For v > -128.5, lround(v) + 128 ==
+ * trunc(v + 128.5) (they differ only on exact negative ties, which a sum of products with the
+ * six-decimal table does not produce); below that both clamp to 0. */
 __device__ __forceinline__ uint32_t to_sample(double v) {
-    double r = v + copysign(0.5, v);
-    int i = (int)r + 128; /* conversion truncates toward zero */
+    int i = (int)(v + 128.5); /* conversion truncates toward zero */
     return (uint32_t)min(max(i, 0), 255);
 }
 
 /*
- * Exact integer form of the reference colour transform (src/image.c:44-48, doubles, clamp,
+ * Exact integer form of the reference colour transform (src/image.c:44-48: doubles, clamp,
  * truncating store).  For Y in 0..255 and cb, cr in -128..127:
  *   R = clamp(Y + floor(1.402 cr)), B = clamp(Y + floor(1.772 cb)),
  *   G = clamp(Y + floor(-(34414 cb + 71414 cr) / 100000))
- * The real-valued sums are never within 1e-6 of an integer unless they are integers, so the
- * double evaluation and the exact rational floor agree except where the real value IS an
- * integer (cb,cr = -100,100 and 100,-100); those are handled below and the whole function is
- * checked over all 2^24 triples against the oracle (tests/test_gpu_parity.py).
+ * The real-valued sums are at least 1e-5 away from an integer unless they ARE integers, so the
+ * reference's double evaluation and the exact rational floor agree -- except for the one
+ * (cb, cr) pair noted below.  The floors are taken in f32 on values shifted positive, with
+ * proven margins (R, B: fractions are multiples of 0.002, f32 error < 4e-5; G: the quotient
+ * (n/32 + 0.5) / 3125 keeps fractions inside [1.5e-4, 1 - 1.5e-4], f32 error < 5e-5).  The whole
+ * function is checked over all 2^24 (Y, Cb, Cr) against the oracle (tests/test_gpu_parity.py).
  */
 struct ChromaTerms { int dr, dg, db; uint32_t exc; };
 __device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
     int cb = cbv - 128, cr = crv - 128;
     ChromaTerms t;
-    /* floor(n / 1000) and floor(n / 100000) by multiply-high on a numerator shifted positive:
-     * ceil(2^32/1000) = 4294968 is exact for n < 6e6, ceil(2^48/1e5) = 2814749768 for n < 2^26 */
-    t.dr = (int)__umulhi((uint32_t)(1402 * cr + 256000), 4294968u) - 256;
-    t.db = (int)__umulhi((uint32_t)(1772 * cb + 256000), 4294968u) - 256;
-    uint32_t n = (uint32_t)(25600000 - (34414 * cb + 71414 * cr));
-    t.dg = (int)(((uint64_t)n * 2814749768ull) >> 48) - 256;
+    t.dr = (int)fmaf(1.402f, (float)cr, 256.0f) - 256;
+    t.db = (int)fmaf(1.772f, (float)cb, 256.0f) - 256;
+    /* floor(n / 100000) = floor(floor(n / 32) / 3125), n = 25600000 - (34414 cb + 71414 cr) > 0 */
+    uint32_t m = (uint32_t)(25600000 - __mul24(34414, cb) - __mul24(71414, cr)) >> 5;
+    const float inv = 1.0f / 3125.0f;
+    t.dg = (int)fmaf((float)m, inv, 0.5f * inv) - 256;
     /* the one place where double rounding in src/image.c:46 shows: Cb = 28, Cr = 228 gives
      * exactly Y - 37 in real arithmetic, but (Y + 34.414) - 71.414 in doubles lands just below
      * the integer for Y in 94..165, and the truncating store then yields one less */
@@ -797,17 +804,63 @@ __device__ __forceinline__ int green_fix(const ChromaTerms &t, int Y) {
 
 __device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
 
-#define PIX_ROW_PAD 8u            /* bytes added to each sample-tile row */
-#define TR_BLK_BYTES (512u + 64u) /* transpose buffer per 8x8 block of doubles */
+/* 4 pixels that share their chroma in pairs (4:2:0) or not (4:4:4) -> 12 output bytes */
+struct Px4 { uint32_t d0, d1, d2; };
+template <bool OUT_YCBCR>
+__device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const uint32_t crv[4], int nterms) {
+    uint32_t o[12];
+    ChromaTerms ct[4];
+    if (!OUT_YCBCR) {
+        ct[0] = chroma_terms((int)cbv[0], (int)crv[0]);
+        if (nterms == 4) {
+            ct[1] = chroma_terms((int)cbv[1], (int)crv[1]);
+            ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
+            ct[3] = chroma_terms((int)cbv[3], (int)crv[3]);
+        } else {
+            ct[1] = ct[0];
+            ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
+            ct[3] = ct[2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int Y = (int)((y4 >> (8 * i)) & 255u);
+        if (OUT_YCBCR) { o[3 * i] = (uint32_t)Y; o[3 * i + 1] = cbv[i]; o[3 * i + 2] = crv[i]; }
+        else {
+            o[3 * i] = clamp255(Y + ct[i].dr);
+            o[3 * i + 1] = clamp255(Y + ct[i].dg - green_fix(ct[i], Y));
+            o[3 * i + 2] = clamp255(Y + ct[i].db);
+        }
+    }
+    Px4 r;
+    r.d0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    r.d1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+    r.d2 = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+    return r;
+}
+
+__device__ __forceinline__ void store_px4(uint8_t *out, size_t off, const Px4 &v, bool aligned, uint32_t npx) {
+    if (aligned) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + off);
+        dst[0] = v.d0; dst[1] = v.d1; dst[2] = v.d2;
+    } else {
+        const uint32_t w[3] = {v.d0, v.d1, v.d2};
+        for (uint32_t i = 0; i < npx * 3; ++i) out[off + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+#define PIX_ROW (JD_STRIP_PX + 8u) /* bytes per sample-tile row (+8 spreads the rows over banks) */
+#define TR_BLK 64u                 /* doubles per 8x8 block in the transpose buffer */
 
 /*
  * k_pixel: one work-group per strip of an MCU row (JD_STRIP_PX pixels wide).
- *   phase 1: 8 lanes per data unit.  Lane u loads column u of the block (coefficients are stored
+ *   phase 1: 8 lanes per data unit.  Lane u loads column u of the unit (coefficients are stored
  *            column-major: 16 contiguous bytes), dequantises, does the vertical 8-point
- *            transform, transposes through LDS, does the horizontal transform for row y, rounds
- *            and writes 8 samples of one row into the component's sample tile in LDS.
- *   phase 2: 4 pixels per lane: gather Y/Cb/Cr (replicated chroma), colour transform, one
- *            12-byte store; 64 lanes cover 768 contiguous bytes of an output row.
+ *            transform, transposes through LDS (within its wave), does the horizontal transform
+ *            for row y, rounds and writes 8 samples of one row into the component's sample tile.
+ *   phase 2: 4 pixels per lane (x 2 rows when chroma is shared vertically): gather Y/Cb/Cr
+ *            (replicated chroma), colour transform, 12-byte stores; 64 lanes cover 768
+ *            contiguous bytes of an output row.
  * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces).
  */
 template <bool OUT_YCBCR>
@@ -815,8 +868,8 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
                                                uint8_t *__restrict__ pix) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tr[32 * TR_BLK_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[3][16 * (JD_STRIP_PX + PIX_ROW_PAD)];
+    __shared__ __attribute__((aligned(16))) double s_tr[32 * TR_BLK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[3][16 * PIX_ROW];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
 
     const jd_pix_wg wg = wgs[blockIdx.x];
@@ -831,6 +884,10 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
     /* ---- phase 1 ---- */
     const uint32_t l = tid & 7u, slot = tid >> 3;
     const size_t mcu0 = (size_t)wg.mcu_row * im.mcus_x + wg.mcu_col0;
+    /* transpose buffer: element (y, u) of slot s at s*64 + y*8 + (((u + y) & 7) ^ (s & 3)):
+     * the 32 lanes of a half-wave that read (their y, step u) hit 32 different bank pairs */
+    double *tr = s_tr + slot * TR_BLK;
+    const uint32_t sx = slot & 3u;
     for (uint32_t j0 = 0; j0 < nblk; j0 += 32) {
         uint32_t j = j0 + slot;
         bool act = j < nblk;
@@ -845,81 +902,96 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int lo = (int)(int16_t)(rw[i] & 0xFFFFu), hi = (int)(int16_t)(rw[i] >> 16);
-                col[2 * i] = (double)(lo * (int)(qw[i] & 0xFFFFu));       /* src/decoding.c:46,65 */
-                col[2 * i + 1] = (double)(hi * (int)(qw[i] >> 16));
+                col[2 * i] = (double)__mul24(lo, (int)(qw[i] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                col[2 * i + 1] = (double)__mul24(hi, (int)(qw[i] >> 16));
             }
-            idct8(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
-            double *tr = reinterpret_cast<double *>(s_tr + slot * TR_BLK_BYTES);
+            idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
 #pragma unroll
-            for (int y = 0; y < 8; ++y) tr[y * 8 + l] = t[y];
+            for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
         }
-        __syncthreads();
+        /* the 8 lanes of a unit sit in one wave: a wave-level fence orders the exchange */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (act) {
-            const double *tr = reinterpret_cast<const double *>(s_tr + slot * TR_BLK_BYTES);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + u];
-            idct8(col, t); /* horizontal: row y = l, t[x] */
+            for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
+            idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
             uint32_t w0 = 0, w1 = 0;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                w0 |= to_sample(t[x] * 0.25) << (8 * x);          /* src/decoding.c:83: sum / 4 */
-                w1 |= to_sample(t[x + 4] * 0.25) << (8 * x);
+                w0 |= to_sample(t[x]) << (8 * x);
+                w1 |= to_sample(t[x + 4]) << (8 * x);
             }
             uint32_t row = im.blk_v[b] * 8u + l;
             uint32_t colpx = (m * im.comp_H[c] + im.blk_h[b]) * 8u;
-            *reinterpret_cast<uint2 *>(&s_tile[c][row * (JD_STRIP_PX + PIX_ROW_PAD) + colpx]) = make_uint2(w0, w1);
+            *reinterpret_cast<uint2 *>(&s_tile[c][row * PIX_ROW + colpx]) = make_uint2(w0, w1);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __syncthreads();
 
     /* ---- phase 2 ---- */
     const uint32_t W = im.width, H = im.height;
     const uint32_t x0 = wg.mcu_col0 * 8u * maxH, y0 = wg.mcu_row * 8u * maxV;
     const uint32_t rows = min(8u * maxV, H - y0);
     const uint32_t g = tid & 63u, x = x0 + 4u * g;
-    /* per component: horizontal / vertical replication shift (maxH/H in {1,2}: src/jpeg.c:82) */
-    uint32_t hs[3], vs[3], ch[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
-    }
     uint8_t *out = pix + im.pix_off;
-    const bool fast = ((W & 3u) == 0);
-    if (x < W && 4u * g < strip_mcus * 8u * maxH) {
+    const bool aligned = ((W & 3u) == 0);
+    if (!(x < W && 4u * g < strip_mcus * 8u * maxH)) return;
+    const uint32_t npx = min(4u, W - x);
+    const uint32_t mode = im.pix_mode;
+    if (mode == JD_PIX_420) {
+        /* lane: 4 pixels x 2 rows sharing one chroma row */
+        for (uint32_t rp = tid >> 6; 2u * rp < rows; rp += 4) {
+            uint32_t cbp = *reinterpret_cast<const uint16_t *>(&s_tile[1][rp * PIX_ROW + 2u * g]);
+            uint32_t crp = *reinterpret_cast<const uint16_t *>(&s_tile[2][rp * PIX_ROW + 2u * g]);
+            const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
+            const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
+#pragma unroll
+            for (uint32_t dy = 0; dy < 2; ++dy) {
+                uint32_t r = 2u * rp + dy;
+                if (r < rows) {
+                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&s_tile[0][r * PIX_ROW + 4u * g]);
+                    Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
+                    store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                }
+            }
+        }
+    } else if (mode == JD_PIX_444) {
         for (uint32_t r = tid >> 6; r < rows; r += 4) {
-            uint32_t s[3][4]; /* s[channel][pixel] */
+            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&s_tile[0][r * PIX_ROW + 4u * g]);
+            uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&s_tile[1][r * PIX_ROW + 4u * g]);
+            uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&s_tile[2][r * PIX_ROW + 4u * g]);
+            const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
+            const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
+            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
+            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+        }
+    } else {
+        /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
+         * replication shift per component: maxH/H, maxV/V in {1,2} (src/jpeg.c:82) */
+        uint32_t hs[3], vs[3], ch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
+        }
+        for (uint32_t r = tid >> 6; r < rows; r += 4) {
+            uint32_t s[3][4]; /* s[channel][pixel]; channel = component id - 1 (src/decoding.c:107) */
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const uint8_t *tp = &s_tile[c][(r >> vs[c]) * (JD_STRIP_PX + PIX_ROW_PAD)];
+                const uint8_t *tp = &s_tile[c][(r >> vs[c]) * PIX_ROW];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     uint32_t v = tp[(4u * g + i) >> hs[c]];
-                    /* channel = component id - 1 (src/decoding.c:107) */
                     if (ch[c] == 0) s[0][i] = v; else if (ch[c] == 1) s[1][i] = v; else s[2][i] = v;
                 }
             }
-            uint32_t o[12];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (OUT_YCBCR) { o[3 * i] = s[0][i]; o[3 * i + 1] = s[1][i]; o[3 * i + 2] = s[2][i]; }
-                else {
-                    ChromaTerms ct = chroma_terms((int)s[1][i], (int)s[2][i]);
-                    o[3 * i] = clamp255((int)s[0][i] + ct.dr);
-                    o[3 * i + 1] = clamp255((int)s[0][i] + ct.dg - green_fix(ct, (int)s[0][i]));
-                    o[3 * i + 2] = clamp255((int)s[0][i] + ct.db);
-                }
-            }
-            size_t off = ((size_t)(y0 + r) * W + x) * 3;
-            if (fast) {
-                uint32_t d0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-                uint32_t d1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
-                uint32_t d2 = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
-                uint32_t *dst = reinterpret_cast<uint32_t *>(out + off);
-                dst[0] = d0; dst[1] = d1; dst[2] = d2;
-            } else {
-                uint32_t npx = min(4u, W - x);
-                for (uint32_t i = 0; i < npx * 3; ++i) out[off + i] = (uint8_t)o[i];
-            }
+            uint32_t y4 = s[0][0] | (s[0][1] << 8) | (s[0][2] << 16) | (s[0][3] << 24);
+            Px4 v = colour4<OUT_YCBCR>(y4, s[1], s[2], 4);
+            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
         }
     }
 }

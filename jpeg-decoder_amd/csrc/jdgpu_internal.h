@@ -106,7 +106,7 @@ typedef struct {
     uint32_t u_off;        /* index of its first entry in the interval-offset array (n_intervals+1 each) */
     uint32_t chunk_off;    /* index of its first raw chunk in the per-chunk arrays */
     uint32_t n_chunks;     /* raw chunks of JD_RAW_CHUNK bytes */
-    uint32_t pad2_;
+    uint32_t pix_mode;     /* JD_PIX_* fast path of the pixel kernel */
     uint32_t lut_off;      /* index of the image's first jd_lut (JD_LUT_SLOTS each) */
     uint32_t mcus_x, mcus_y;
     uint16_t width, height;
@@ -129,6 +129,9 @@ typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK
 #define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
 
 #define JD_STRIP_PX 256u  /* pixel-kernel strip width */
+#define JD_PIX_GENERIC 0u
+#define JD_PIX_420 1u     /* ids 1,2,3 in scan order, Y 2x2, Cb/Cr 1x1 */
+#define JD_PIX_444 2u     /* ids 1,2,3 in scan order, all 1x1 */
 
 /* ---- host preparation (jdgpu_prep.c) -------------------------------------------------------- */
 

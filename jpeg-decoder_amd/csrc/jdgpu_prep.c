@@ -127,6 +127,13 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         }
         if (!ok) { im->ncomp = 0; continue; }
         im->bpm = (uint8_t)b;
+        {
+            int std_ids = d->comp[0].id == 1 && d->comp[1].id == 2 && d->comp[2].id == 3;
+            int c11 = d->comp[1].H == 1 && d->comp[1].V == 1 && d->comp[2].H == 1 && d->comp[2].V == 1;
+            im->pix_mode = JD_PIX_GENERIC;
+            if (std_ids && c11 && d->comp[0].H == 2 && d->comp[0].V == 2) im->pix_mode = JD_PIX_420;
+            if (std_ids && c11 && d->comp[0].H == 1 && d->comp[0].V == 1) im->pix_mode = JD_PIX_444;
+        }
         for (unsigned t = 0; t < 4; ++t)
             for (unsigned k = 0; k < 64; ++k) im->quant[t][jd_zigzag_to_cm[k]] = d->quant[t][k];
         im->mcus_x = (d->width + 8u * maxH - 1) / (8u * maxH);   /* src/jpeg.c:66-75 */
