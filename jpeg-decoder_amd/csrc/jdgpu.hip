@@ -878,26 +878,37 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
     const uint32_t maxH = im.maxH, maxV = im.maxV, bpm = im.bpm;
     const uint32_t strip_mcus = min((uint32_t)(JD_STRIP_PX / (8u * maxH)), im.mcus_x - wg.mcu_col0);
     const uint32_t nblk = strip_mcus * bpm;
+    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 */
     s_q[tid >> 6][tid & 63u] = im.quant[tid >> 6][tid & 63u];
-    __syncthreads();
+    if (tid < JD_MAX_BPM) {
+        uint32_t c = im.blk_comp[tid];
+        s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
+                      ((uint32_t)im.comp_H[c] << 8);
+    }
 
     /* ---- phase 1 ---- */
     const uint32_t l = tid & 7u, slot = tid >> 3;
     const size_t mcu0 = (size_t)wg.mcu_row * im.mcus_x + wg.mcu_col0;
+    /* the strip's data units are consecutive in the coefficient buffer */
+    const int16_t *cbase = coef + ((size_t)im.blk_off + mcu0 * bpm) * 64 + l * 8;
     /* transpose buffer: element (y, u) of slot s at s*64 + y*8 + (((u + y) & 7) ^ (s & 3)):
      * the 32 lanes of a half-wave that read (their y, step u) hit 32 different bank pairs */
     double *tr = s_tr + slot * TR_BLK;
     const uint32_t sx = slot & 3u;
+    /* software pipeline: the loads of the next 32 units are in flight while these are transformed */
+    uint4 raw_next = make_uint4(0, 0, 0, 0);
+    if (slot < nblk) raw_next = *reinterpret_cast<const uint4 *>(cbase + (size_t)slot * 64);
+    __syncthreads();
     for (uint32_t j0 = 0; j0 < nblk; j0 += 32) {
         uint32_t j = j0 + slot;
         bool act = j < nblk;
-        uint32_t m = 0, b = 0, c = 0;
+        const uint4 raw = raw_next;
+        if (j + 32 < nblk) raw_next = *reinterpret_cast<const uint4 *>(cbase + (size_t)(j + 32) * 64);
+        uint32_t m = 0, b = 0, meta = 0;
         double col[8], t[8];
         if (act) {
-            m = j / bpm; b = j - m * bpm; c = im.blk_comp[b];
-            const int16_t *src = coef + ((size_t)im.blk_off + (mcu0 + m) * bpm + b) * 64 + l * 8;
-            uint4 raw = *reinterpret_cast<const uint4 *>(src);
-            uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[im.comp_tq[c]][l * 8]);
+            m = j / bpm; b = j - m * bpm; meta = s_meta[b];
+            uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
             const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -923,9 +934,9 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
                 w0 |= to_sample(t[x]) << (8 * x);
                 w1 |= to_sample(t[x + 4]) << (8 * x);
             }
-            uint32_t row = im.blk_v[b] * 8u + l;
-            uint32_t colpx = (m * im.comp_H[c] + im.blk_h[b]) * 8u;
-            *reinterpret_cast<uint2 *>(&s_tile[c][row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+            uint32_t row = ((meta >> 6) & 3u) * 8u + l;
+            uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
+            *reinterpret_cast<uint2 *>(&s_tile[meta & 3u][row * PIX_ROW + colpx]) = make_uint2(w0, w1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
