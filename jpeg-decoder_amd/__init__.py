@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from . import synth  # noqa: F401  (workload generator, re-exported)
+from . import shard, synth  # noqa: F401  (sharding policy, workload generator)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpegamd.so")
