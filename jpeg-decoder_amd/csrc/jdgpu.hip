@@ -322,28 +322,48 @@ struct BitReader {
     const uint32_t *own, *nxt; /* word 0 of this / the next segment; consecutive words are 64 dwords apart */
     uint64_t buf;              /* next bits, left aligned */
     uint32_t cnt;              /* valid bits in buf (>= 33 between symbols) */
-    uint32_t wi;               /* next word to prefetch */
-    uint32_t q1, q2, q3;       /* prefetched words wi-3, wi-2, wi-1 */
+    uint32_t q1, q2;           /* the next two words (raw, big-endian) */
+    uint32_t ql, wl;           /* the word after those and its index; (re)loaded every step */
 
+    /* raw (big-endian) word w; the byte swap is done when the word is USED, so that the load
+     * stays in flight instead of being waited for at once */
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
         const uint32_t *p = w < JD_SEG_WORDS ? own + (size_t)w * 64u : nxt + (size_t)(w - JD_SEG_WORDS) * 64u;
-        return __builtin_bswap32(*p);
+        return *p;
     }
     __device__ __forceinline__ void init(uint32_t p) {
         uint32_t w = p >> 5;
-        buf = (((uint64_t)word(w) << 32) | word(w + 1)) << (p & 31u);
+        uint32_t w0 = word(w), w1 = word(w + 1);
+        q1 = word(w + 2); q2 = word(w + 3); wl = w + 4; ql = word(wl);
+        buf = (((uint64_t)__builtin_bswap32(w0) << 32) | __builtin_bswap32(w1)) << (p & 31u);
         cnt = 64u - (p & 31u);
-        q1 = word(w + 2); q2 = word(w + 3); q3 = word(w + 4);
-        wi = w + 5;
     }
     __device__ __forceinline__ uint32_t top() const { return (uint32_t)(buf >> 32); }
-    __device__ __forceinline__ void consume(uint32_t n) { /* n <= 31 */
+    /* drop n <= 31 bits; branch-free refill from the register queue */
+    __device__ __forceinline__ void advance(uint32_t n) {
+        buf <<= n;
+        cnt -= n;
+        const bool need = cnt <= 32u;
+        uint64_t ins = (uint64_t)__builtin_bswap32(q1) << ((32u - cnt) & 31u);
+        buf |= need ? ins : 0ull;
+        cnt += need ? 32u : 0u;
+        q1 = need ? q2 : q1;
+        q2 = need ? ql : q2;      /* ql was loaded a step ago: its latency is off the critical path */
+        wl += need ? 1u : 0u;
+    }
+    /* unconditional (re)load of the queue tail: no divergent merge ever touches a load that is
+     * still in flight, so the only wait is one whole step after the issue */
+    __device__ __forceinline__ void prefetch() { ql = word(wl); }
+    /* the form for a kernel at full occupancy (k_huff_sync, 8 waves/SIMD): refill and reload
+     * only when a word was used up; the wait that follows the load is hidden by the other
+     * waves and costs less than an extra load in every step */
+    __device__ __forceinline__ void consume(uint32_t n) {
         buf <<= n;
         cnt -= n;
         if (cnt <= 32u) {
-            buf |= (uint64_t)q1 << (32u - cnt);
+            buf |= (uint64_t)__builtin_bswap32(q1) << (32u - cnt);
             cnt += 32u;
-            q1 = q2; q2 = q3; q3 = word(wi); ++wi;
+            q1 = q2; q2 = ql; ++wl; ql = word(wl);
         }
     }
 };
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
                 }
                 if (store) *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
                 p += tot;
-                R.consume(tot);
+                R.advance(tot);
                 if (k >= 64u) {
                     finished = own; fB = B;
                     k = 0; own = true; ++B;
@@ -696,6 +716,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
                 }
             }
         }
+        R.prefetch(); /* all lanes, outside the divergent step */
         /* ---- flush the units completed in this step (wave-synchronous) ---- */
         uint64_t fm = __ballot(finished);
         if (fm) {
