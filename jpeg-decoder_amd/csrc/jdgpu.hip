@@ -610,7 +610,7 @@ __device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
     return lane * WBUF_BYTES + ((((idx >> 3) + lane) & 7u) << 4) + ((idx & 7u) << 1);
 }
 
-__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__restrict__ imgs,
+__global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
                                                            const uint8_t *__restrict__ clean,
                                                            const uint32_t *__restrict__ seg_info,
@@ -623,9 +623,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_write(const jd_image *__res
                                                            uint32_t *__restrict__ status) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
     __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[JD_WG_SEGS * WBUF_BYTES];
-    __shared__ uint32_t s_qblk[JD_WG_SEGS];   /* per wave: global unit index of the r-th finished unit */
-    __shared__ uint8_t s_qlane[JD_WG_SEGS];   /* per wave: lane (within the work-group) that holds it */
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[JD_WWG_SEGS * WBUF_BYTES];
+    __shared__ uint32_t s_qblk[JD_WWG_SEGS];   /* per wave: global unit index of the r-th finished unit */
+    __shared__ uint8_t s_qlane[JD_WWG_SEGS];   /* per wave: lane (within the work-group) that holds it */
     __shared__ uint16_t s_blk[16];
     __shared__ uint8_t s_cm[64];
 
@@ -1054,7 +1054,7 @@ struct jdgpu_batch {
     int4 *d_cnt, *d_start_dc;
     int2 *d_start_blk;
     int16_t *d_coef;
-    jd_huff_wg *d_hwg;
+    jd_huff_wg *d_hwg, *d_wwg;
     jd_pix_wg *d_pwg;
     jd_raw_wg *d_rwg;
     uint2 *d_chunk_cnt, *d_chunk_base;
@@ -1125,7 +1125,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_wg_exit[0]);
     hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt);
     hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
-    hipFree(b->d_rwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
+    hipFree(b->d_rwg); hipFree(b->d_wwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
     if (b->h_changed) hipHostFree(b->h_changed);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -1145,7 +1145,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_wg_exit[0] = b->d_wg_exit[1] = b->d_status = b->d_changed = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
     for (auto &e : b->ev) e = nullptr;
     TRY(jd_plan_build(descs, n, &b->plan, g_err, sizeof g_err));
     jd_plan &P = b->plan;
@@ -1174,6 +1174,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
     TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
+    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg));
     TRY(dalloc(&b->d_chunk_cnt, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_chunk_base, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_ivl_u, (size_t)P.n_u));
@@ -1191,6 +1192,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemset(b->d_pix, 0, (size_t)P.pix_bytes + 256));
     HIPTRY(hipMemset(b->d_status, 0, (n ? n : 1) * 4));
     /* the host copies of the bulky arrays are not needed any more */
@@ -1242,8 +1244,8 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
     if (P.n_hwg)
-        hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
-                           b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+        hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
+                           b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
     if (P.n_pwg) {
         if (b->flags & JDGPU_OUT_YCBCR)
@@ -1275,8 +1277,8 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, s));
         enqueue_huffman(b, false);
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
-        hipLaunchKernelGGL(k_huff_write, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
-                           b->d_hwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+        hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
+                           b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         if (b->flags & JDGPU_OUT_YCBCR)
             hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(256), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
         else

@@ -23,7 +23,8 @@ extern "C" {
 #endif
 #define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 512 B  */
 #define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 4096 b */
-#define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group */
+#define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group, sync kernels */
+#define JD_WWG_SEGS    256u                   /* ... of the coefficient-write kernel (512 measured slower: ragged last group per image) */
 #define JD_MAX_BPM     12u                    /* data units per MCU: 3 components of at most 2x2 */
 #define JD_LUT_BITS    10u                    /* primary Huffman lookup width */
 #define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
@@ -145,6 +146,7 @@ typedef struct {
     uint32_t n_segs_cap;     /* total segment capacity */
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
+    jd_huff_wg *wwg; uint32_t n_wwg;   /* same segments in groups of JD_WWG_SEGS */
     jd_pix_wg *pwg;  uint32_t n_pwg;
     jd_raw_wg *rwg;  uint32_t n_rwg;
     uint32_t n_u;            /* entries of the interval-offset array */

@@ -76,7 +76,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
 
     size_t raw = 0, clean = 0, pix = 0;
     uint64_t blk = 0;
-    uint32_t segs = 0, ivls = 0, nh = 0, np = 0, nr = 0, nu = 0;
+    uint32_t segs = 0, ivls = 0, nh = 0, np = 0, nr = 0, nu = 0, nw = 0;
     for (size_t i = 0; i < n; ++i) {
         const jdgpu_image_desc *d = &descs[i];
         jd_image *im = &P->img[i];
@@ -152,6 +152,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         nu += im->n_intervals + 1; nr += im->n_chunks;
         segs += im->seg_cap; ivls += im->n_intervals; blk += im->n_blocks;
         nh += (im->seg_cap + JD_WG_SEGS - 1) / JD_WG_SEGS;
+        nw += (im->seg_cap + JD_WWG_SEGS - 1) / JD_WWG_SEGS;
         uint32_t strip = JD_STRIP_PX / (8u * maxH);
         np += im->mcus_y * ((im->mcus_x + strip - 1) / strip);
     }
@@ -159,17 +160,20 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
     P->n_segs_cap = segs; P->n_intervals = ivls; P->total_blocks = blk; P->pix_bytes = pix;
     P->n_hwg = nh; P->n_pwg = np; P->n_rwg = nr; P->n_u = nu;
     P->rwg = calloc(nr ? nr : 1, sizeof *P->rwg);
+    P->n_wwg = nw;
+    P->wwg = calloc(nw ? nw : 1, sizeof *P->wwg);
     P->raw = calloc(P->raw_bytes, 1);
     P->hwg = calloc(nh ? nh : 1, sizeof *P->hwg);
     P->pwg = calloc(np ? np : 1, sizeof *P->pwg);
-    if (!P->raw || !P->hwg || !P->pwg || !P->rwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
-    nh = np = nr = 0;
+    if (!P->raw || !P->hwg || !P->pwg || !P->rwg || !P->wwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+    nh = np = nr = nw = 0;
     for (size_t i = 0; i < n; ++i) {
         jd_image *im = &P->img[i];
         if (!im->ncomp) continue;
         memcpy(P->raw + im->raw_off, descs[i].scan, descs[i].scan_len);
         for (uint32_t ch = 0; ch < im->n_chunks; ++ch) { P->rwg[nr].img = (uint32_t)i; P->rwg[nr].chunk = ch; ++nr; }
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
+        for (uint32_t s = 0; s < im->seg_cap; s += JD_WWG_SEGS) { P->wwg[nw].img = (uint32_t)i; P->wwg[nw].seg0 = s; ++nw; }
         uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
         for (uint32_t r = 0; r < im->mcus_y; ++r)
             for (uint32_t c = 0; c < im->mcus_x; c += strip) {
@@ -260,7 +264,7 @@ long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsig
 }
 
 void jd_plan_free(jd_plan *P) {
-    free(P->img); free(P->luts); free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg);
+    free(P->img); free(P->luts); free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg);
     free(P->clean); free(P->seg_info);
     memset(P, 0, sizeof *P);
 }
