@@ -13,7 +13,7 @@ import numpy as np
 from . import shard, synth  # noqa: F401  (sharding policy, workload generator)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpegamd.so")
+LIB_PATH = os.environ.get("JPEGAMD_LIB") or os.path.join(_HERE, "libjpegamd.so")  # override: A/B builds only
 
 # status / flag values of include/jpeg_gpu.h
 OK = 0

@@ -783,11 +783,12 @@ __device__ __forceinline__ void idct8(const double in[8], double out[8]) {
     out[3] = E3 + O3; out[4] = E3 - O3;
 }
 
-/* src/decoding.c:99: clamp(lround(v) + 128, 0, 255).  For v > -128.5, lround(v) + 128 ==
- * trunc(v + 128.5) (they differ only on exact negative ties, which a sum of products with the
- * six-decimal table does not produce); below that both clamp to 0. */
+/* src/decoding.c:99: clamp(lround(v) + 128, 0, 255).  Adding 1.5 * 2^52 + 128 to v leaves
+ * RN(v) + 128 in the low mantissa word (|v| << 2^31): round-to-nearest, which equals lround
+ * except on exact ties -- and a sum of products with the six-decimal table is never an exact
+ * half-integer.  One f64 add, no conversion instruction. */
 __device__ __forceinline__ uint32_t to_sample(double v) {
-    int i = (int)(v + 128.5); /* conversion truncates toward zero */
+    int i = __double2loint(v + (6755399441055744.0 + 128.0));
     return (uint32_t)min(max(i, 0), 255);
 }
 
@@ -870,133 +871,150 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t off, const Px4 &v
     }
 }
 
-#define PIX_ROW (JD_STRIP_PX + 8u) /* bytes per sample-tile row (+8 spreads the rows over banks) */
+#define SUB_PX 64u                 /* pixels per wave: each wave owns a 64-pixel-wide part of the strip */
+#define PIX_ROW (SUB_PX + 8u)      /* bytes per sample-tile row (+8 spreads the rows over banks) */
+#define PLANE_BYTES (16u * PIX_ROW)
 #define TR_BLK 64u                 /* doubles per 8x8 block in the transpose buffer */
 
+#define WAVE_SYNC()                                                   \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
+
 /*
- * k_pixel: one work-group per strip of an MCU row (JD_STRIP_PX pixels wide).
+ * k_pixel: one work-group per strip of an MCU row (JD_STRIP_PX pixels wide); each of its
+ * waves owns a 64-pixel-wide part and runs both phases on it without any work-group barrier:
  *   phase 1: 8 lanes per data unit.  Lane u loads column u of the unit (coefficients are stored
  *            column-major: 16 contiguous bytes), dequantises, does the vertical 8-point
- *            transform, transposes through LDS (within its wave), does the horizontal transform
+ *            transform, transposes through LDS (within the wave), does the horizontal transform
  *            for row y, rounds and writes 8 samples of one row into the component's sample tile.
  *   phase 2: 4 pixels per lane (x 2 rows when chroma is shared vertically): gather Y/Cb/Cr
- *            (replicated chroma), colour transform, 12-byte stores; 64 lanes cover 768
+ *            (replicated chroma), colour transform, one 12-byte store; 16 lanes cover 192
  *            contiguous bytes of an output row.
  * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces).
  */
 template <bool OUT_YCBCR>
-__global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs,
+__global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__restrict__ imgs,
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
                                                uint8_t *__restrict__ pix) {
-    __shared__ __attribute__((aligned(16))) double s_tr[32 * TR_BLK];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[3][16 * PIX_ROW];
+    __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][3 * PLANE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
+    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 */
 
     const jd_pix_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t maxH = im.maxH, maxV = im.maxV, bpm = im.bpm;
-    const uint32_t strip_mcus = min((uint32_t)(JD_STRIP_PX / (8u * maxH)), im.mcus_x - wg.mcu_col0);
-    const uint32_t nblk = strip_mcus * bpm;
-    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 */
-    s_q[tid >> 6][tid & 63u] = im.quant[tid >> 6][tid & 63u];
+    const uint32_t sub_mcus = SUB_PX / (8u * maxH);
+    for (uint32_t i = tid; i < 256; i += 64 * JD_PIX_WAVES) s_q[i >> 6][i & 63u] = im.quant[i >> 6][i & 63u];
     if (tid < JD_MAX_BPM) {
         uint32_t c = im.blk_comp[tid];
         s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
                       ((uint32_t)im.comp_H[c] << 8);
     }
+    const uint32_t mcu_first = wg.mcu_col0 + wave * sub_mcus;          /* first MCU column of this wave */
+    const uint32_t my_mcus = mcu_first < im.mcus_x ? min(sub_mcus, im.mcus_x - mcu_first) : 0u;
+    const uint32_t nblk = my_mcus * bpm;
 
     /* ---- phase 1 ---- */
-    const uint32_t l = tid & 7u, slot = tid >> 3;
-    const size_t mcu0 = (size_t)wg.mcu_row * im.mcus_x + wg.mcu_col0;
-    /* the strip's data units are consecutive in the coefficient buffer */
-    const int16_t *cbase = coef + ((size_t)im.blk_off + mcu0 * bpm) * 64 + l * 8;
+    const uint32_t l = lane & 7u, slot = lane >> 3;
+    /* the wave's data units are consecutive in the coefficient buffer */
+    const int16_t *cbase = coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64 + l * 8;
     /* transpose buffer: element (y, u) of slot s at s*64 + y*8 + (((u + y) & 7) ^ (s & 3)):
      * the 32 lanes of a half-wave that read (their y, step u) hit 32 different bank pairs */
-    double *tr = s_tr + slot * TR_BLK;
+    double *tr = s_tr + (wave * 8u + slot) * TR_BLK;
+    uint8_t *tile = s_tile[wave];
     const uint32_t sx = slot & 3u;
-    /* software pipeline: the loads of the next 32 units are in flight while these are transformed */
-    uint4 raw_next = make_uint4(0, 0, 0, 0);
-    if (slot < nblk) raw_next = *reinterpret_cast<const uint4 *>(cbase + (size_t)slot * 64);
+    /* all coefficient loads of up to three 8-unit steps are issued before the first transform:
+     * ~3 KB in flight per wave is what it takes to cover HBM latency at 20 waves per CU */
     __syncthreads();
-    for (uint32_t j0 = 0; j0 < nblk; j0 += 32) {
-        uint32_t j = j0 + slot;
-        bool act = j < nblk;
-        const uint4 raw = raw_next;
-        if (j + 32 < nblk) raw_next = *reinterpret_cast<const uint4 *>(cbase + (size_t)(j + 32) * 64);
-        uint32_t m = 0, b = 0, meta = 0;
-        double col[8], t[8];
-        if (act) {
-            m = j / bpm; b = j - m * bpm; meta = s_meta[b];
-            uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
-            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+    if (nblk == 0) return;
+    for (uint32_t r0 = 0; r0 < nblk; r0 += 24) {
+        uint4 rawv[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int lo = (int)(int16_t)(rw[i] & 0xFFFFu), hi = (int)(int16_t)(rw[i] >> 16);
-                col[2 * i] = (double)__mul24(lo, (int)(qw[i] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                col[2 * i + 1] = (double)__mul24(hi, (int)(qw[i] >> 16));
-            }
-            idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
-#pragma unroll
-            for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
+        for (int i = 0; i < 3; ++i) {
+            uint32_t j = r0 + 8u * i + slot;
+            rawv[i] = make_uint4(0, 0, 0, 0);
+            if (j < nblk) rawv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
         }
-        /* the 8 lanes of a unit sit in one wave: a wave-level fence orders the exchange */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (act) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
-            idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
-            uint32_t w0 = 0, w1 = 0;
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t j = r0 + 8u * i + slot;
+            if (r0 + 8u * i >= nblk) break; /* wave-uniform */
+            const bool act = j < nblk;
+            const uint4 raw = rawv[i];
+            uint32_t m = 0, b = 0, meta = 0;
+            double col[8], t[8];
+            if (act) {
+                m = j / bpm; b = j - m * bpm; meta = s_meta[b];
+                uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
+                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                w0 |= to_sample(t[x]) << (8 * x);
-                w1 |= to_sample(t[x + 4]) << (8 * x);
+                for (int q = 0; q < 4; ++q) {
+                    int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
+                    col[2 * q] = (double)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                    col[2 * q + 1] = (double)__mul24(hi, (int)(qw[q] >> 16));
+                }
+                idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
+#pragma unroll
+                for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
             }
-            uint32_t row = ((meta >> 6) & 3u) * 8u + l;
-            uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
-            *reinterpret_cast<uint2 *>(&s_tile[meta & 3u][row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+            WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
+                idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
+                uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    w0 |= to_sample(t[x]) << (8 * x);
+                    w1 |= to_sample(t[x + 4]) << (8 * x);
+                }
+                uint32_t row = ((meta >> 6) & 3u) * 8u + l;
+                uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
+                *reinterpret_cast<uint2 *>(&tile[(meta & 3u) * PLANE_BYTES + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+            }
+            WAVE_SYNC();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
 
     /* ---- phase 2 ---- */
     const uint32_t W = im.width, H = im.height;
-    const uint32_t x0 = wg.mcu_col0 * 8u * maxH, y0 = wg.mcu_row * 8u * maxV;
+    const uint32_t x0 = mcu_first * 8u * maxH, y0 = wg.mcu_row * 8u * maxV;
     const uint32_t rows = min(8u * maxV, H - y0);
-    const uint32_t g = tid & 63u, x = x0 + 4u * g;
+    const uint32_t g = lane & 15u, rq = lane >> 4, x = x0 + 4u * g;
     uint8_t *out = pix + im.pix_off;
     const bool aligned = ((W & 3u) == 0);
-    if (!(x < W && 4u * g < strip_mcus * 8u * maxH)) return;
+    if (!(x < W && 4u * g < my_mcus * 8u * maxH)) return;
     const uint32_t npx = min(4u, W - x);
     const uint32_t mode = im.pix_mode;
+    const uint8_t *tY = tile, *tB = tile + PLANE_BYTES, *tR = tile + 2 * PLANE_BYTES;
     if (mode == JD_PIX_420) {
         /* lane: 4 pixels x 2 rows sharing one chroma row */
-        for (uint32_t rp = tid >> 6; 2u * rp < rows; rp += 4) {
-            uint32_t cbp = *reinterpret_cast<const uint16_t *>(&s_tile[1][rp * PIX_ROW + 2u * g]);
-            uint32_t crp = *reinterpret_cast<const uint16_t *>(&s_tile[2][rp * PIX_ROW + 2u * g]);
+        for (uint32_t rp = rq; 2u * rp < rows; rp += 4) {
+            uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[rp * PIX_ROW + 2u * g]);
+            uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[rp * PIX_ROW + 2u * g]);
             const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
             const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
 #pragma unroll
             for (uint32_t dy = 0; dy < 2; ++dy) {
                 uint32_t r = 2u * rp + dy;
                 if (r < rows) {
-                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&s_tile[0][r * PIX_ROW + 4u * g]);
+                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
                     Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
                     store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
                 }
             }
         }
     } else if (mode == JD_PIX_444) {
-        for (uint32_t r = tid >> 6; r < rows; r += 4) {
-            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&s_tile[0][r * PIX_ROW + 4u * g]);
-            uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&s_tile[1][r * PIX_ROW + 4u * g]);
-            uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&s_tile[2][r * PIX_ROW + 4u * g]);
+        for (uint32_t r = rq; r < rows; r += 4) {
+            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
+            uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[r * PIX_ROW + 4u * g]);
+            uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[r * PIX_ROW + 4u * g]);
             const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
             const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
             Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
@@ -1010,11 +1028,11 @@ __global__ __launch_bounds__(256) void k_pixel(const jd_image *__restrict__ imgs
         for (int c = 0; c < 3; ++c) {
             hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
         }
-        for (uint32_t r = tid >> 6; r < rows; r += 4) {
+        for (uint32_t r = rq; r < rows; r += 4) {
             uint32_t s[3][4]; /* s[channel][pixel]; channel = component id - 1 (src/decoding.c:107) */
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const uint8_t *tp = &s_tile[c][(r >> vs[c]) * PIX_ROW];
+                const uint8_t *tp = &tile[c * PLANE_BYTES + (r >> vs[c]) * PIX_ROW];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     uint32_t v = tp[(4u * g + i) >> hs[c]];
@@ -1249,9 +1267,9 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
     if (P.n_pwg) {
         if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(256), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
         else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(256), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[5], st));
     HIPCHK(hipGetLastError());
@@ -1280,9 +1298,9 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(256), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
         else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(256), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
         HIPCHK(hipStreamSynchronize(s));
     }
     for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);

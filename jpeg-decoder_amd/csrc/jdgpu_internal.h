@@ -129,7 +129,10 @@ typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip
 typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */
 #define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
 
-#define JD_STRIP_PX 256u  /* pixel-kernel strip width */
+#ifndef JD_PIX_WAVES
+#define JD_PIX_WAVES 4u    /* waves per pixel-kernel work-group; each wave owns 64 pixels of the strip */
+#endif
+#define JD_STRIP_PX (64u * JD_PIX_WAVES)  /* pixel-kernel strip width */
 #define JD_PIX_GENERIC 0u
 #define JD_PIX_420 1u     /* ids 1,2,3 in scan order, Y 2x2, Cb/Cr 1x1 */
 #define JD_PIX_444 2u     /* ids 1,2,3 in scan order, all 1x1 */
