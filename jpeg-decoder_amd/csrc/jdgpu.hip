@@ -47,11 +47,12 @@ static thread_local char g_err[512] = "";
 
 #define SEG_MASK 0xFFFFu /* valid-bit count in a per-segment word */
 
-/* The clean stream is stored transposed in groups of 64 segments: word w of segment s lives at
- * [(s / 64) * JD_SEG_WORDS + w][s % 64], so the 64 lanes of a wave -- one segment each, all
- * roughly equally far into their segments -- read neighbouring dwords of the same cache lines. */
+/* The clean stream is stored transposed in groups of 64 segments, 16 bytes at a time: bytes
+ * [16q, 16q+16) of segment s live at [(s / 64) * (JD_SEG_BYTES/16) + q][s % 64], so the 64 lanes
+ * of a wave -- one segment each, all roughly equally far into their segments -- read from the
+ * same few cache lines, and the unstuff stage can still store 16 bytes at a time. */
 __host__ __device__ __forceinline__ size_t clean_word_index(uint32_t seg, uint32_t w) {
-    return ((size_t)(seg >> 6) * JD_SEG_WORDS + w) * 64u + (seg & 63u);
+    return (((size_t)(seg >> 6) * (JD_SEG_WORDS / 4u) + (w >> 2)) * 64u + (seg & 63u)) * 4u + (w & 3u);
 }
 __host__ __device__ __forceinline__ size_t clean_byte_addr(uint32_t seg, uint32_t o) {
     return clean_word_index(seg, o >> 2) * 4u + (o & 3u);
@@ -253,10 +254,17 @@ __global__ __launch_bounds__(256) void k_unstuff_layout(jd_image *__restrict__ i
         uint32_t bytes = len > k * JD_SEG_BYTES ? min(JD_SEG_BYTES, len - k * JD_SEG_BYTES) : 0u;
         seg_info[im.seg_off + s] = (bytes * 8u) | (k == 0 ? JD_SEG_FIRST : 0u);
         uint8_t *dst = clean + im.clean_off;
-        for (uint32_t q = bytes; q < JD_SEG_BYTES; ++q) dst[clean_byte_addr(s, q)] = 0xFF;
+        uint32_t q = bytes;
+        for (; q < JD_SEG_BYTES && (q & 15u); ++q) dst[clean_byte_addr(s, q)] = 0xFF;
+        for (; q < JD_SEG_BYTES; q += 16)
+            *reinterpret_cast<uint4 *>(dst + clean_byte_addr(s, q)) = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
 }
 
+/* Kept bytes of one chunk go to their padded position.  Per restart interval present in the
+ * chunk (one, unless markers fall inside it) the bytes are first compacted in LDS at the byte
+ * alignment of their destination, then stored 16 bytes per lane; only the ragged first and last
+ * 16 bytes of a run are stored byte by byte (the neighbouring chunk fills in the rest). */
 __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restrict__ imgs,
                                                          const jd_raw_wg *__restrict__ wgs,
                                                          const uint8_t *__restrict__ raw,
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
                                                          const uint32_t *__restrict__ ivl_seg,
                                                          uint8_t *__restrict__ clean) {
     __shared__ uint32_t s_tmp[8];
+    __shared__ __align__(16) uint8_t s_stage[JD_RAW_CHUNK + 32];
     const jd_raw_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
     RawLane r = raw_lane_load(raw + im.raw_off, im.raw_len, wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
@@ -273,24 +282,47 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
     uint32_t ea, eb, ta, tb;
     wg_exclusive_scan2(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
     const uint2 cb = chunk_base[im.chunk_off + wg.chunk];
-    uint32_t u = cb.x + ea, m = cb.y + eb; /* clean offset (unpadded) and interval of the next kept byte */
-    const uint32_t nI = im.n_intervals, seg_cap = im.seg_cap;
+    const uint32_t u_lo = cb.x, u_hi = cb.x + ta;   /* unpadded clean offsets of the chunk's kept bytes */
+    const uint32_t nI = im.n_intervals;
+    const uint64_t cap = (uint64_t)im.seg_cap * JD_SEG_BYTES;
     const uint32_t *U = ivl_u + im.u_off;
     const uint32_t *S = ivl_seg + im.ivl_off;
     uint8_t *dst = clean + im.clean_off;
-    uint32_t active = keep | mark;
-    int64_t delta = 0; /* padded position = u + delta within the interval */
-    bool have = false;
-    while (active) {
-        uint32_t i = __ffs(active) - 1;
-        active &= active - 1;
-        if (mark >> i & 1u) { ++m; have = false; continue; }
-        if (m >= nI) break; /* behind the marker that ends the data */
-        if (!have) { delta = (int64_t)S[m] * JD_SEG_BYTES - (int64_t)U[m]; have = true; }
-        int64_t pos = (int64_t)u + delta;
-        if (pos >= 0 && pos < (int64_t)seg_cap * JD_SEG_BYTES)
-            dst[clean_byte_addr((uint32_t)(pos / JD_SEG_BYTES), (uint32_t)(pos % JD_SEG_BYTES))] = (uint8_t)r.b[i];
-        ++u;
+    for (uint32_t run = 0; run <= tb; ++run) {
+        const uint32_t m_r = cb.y + run;              /* interval of this run */
+        if (m_r >= nI) break;                         /* behind the marker that ends the data */
+        const uint32_t Um = U[m_r];
+        const uint32_t a = max(Um, u_lo), b = min(U[m_r + 1], u_hi);
+        if (b <= a) continue;
+        const uint64_t shift = (uint64_t)S[m_r] * JD_SEG_BYTES - Um;   /* padded position = u + shift */
+        const uint64_t pos_a = a + shift, pos_b = b + shift, base = pos_a & ~(uint64_t)15;
+        const uint32_t head = (uint32_t)(pos_a - base);
+        {
+            uint32_t u = u_lo + ea, m = cb.y + eb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool kp = (keep >> i) & 1u;
+                if (kp && m == m_r) s_stage[u - a + head] = (uint8_t)r.b[i];
+                u += kp ? 1u : 0u;
+                m += (mark >> i) & 1u;
+            }
+        }
+        __syncthreads();
+        const uint32_t pieces = (uint32_t)((pos_b - base + 15u) >> 4);
+        for (uint32_t q = threadIdx.x; q < pieces; q += 256) {
+            const uint64_t P = base + 16u * (uint64_t)q;
+            if (P + 16u > cap) continue;
+            const uint32_t seg = (uint32_t)(P / JD_SEG_BYTES), o = (uint32_t)(P % JD_SEG_BYTES);
+            uint8_t *d = dst + clean_byte_addr(seg, o);
+            if (P >= pos_a && P + 16u <= pos_b) {
+                *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s_stage + 16u * q);
+            } else {
+                const uint32_t lo = P >= pos_a ? 0u : (uint32_t)(pos_a - P);
+                const uint32_t hi = P + 16u <= pos_b ? 16u : (uint32_t)(pos_b - P);
+                for (uint32_t k = lo; k < hi; ++k) d[k] = s_stage[16u * q + k];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -319,7 +351,7 @@ __device__ __forceinline__ int extend(uint32_t bits, uint32_t size) {
  * (L2 / Infinity Cache latency) are never on the symbol-to-symbol critical path.
  */
 struct BitReader {
-    const uint32_t *own, *nxt; /* word 0 of this / the next segment; consecutive words are 64 dwords apart */
+    const uint32_t *own, *nxt; /* word 0 of this / the next segment (16-byte pieces are 1 KiB apart) */
     uint64_t buf;              /* next bits, left aligned */
     uint32_t cnt;              /* valid bits in buf (>= 33 between symbols) */
     uint32_t q1, q2;           /* the next two words (raw, big-endian) */
@@ -328,8 +360,8 @@ struct BitReader {
     /* raw (big-endian) word w; the byte swap is done when the word is USED, so that the load
      * stays in flight instead of being waited for at once */
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
-        const uint32_t *p = w < JD_SEG_WORDS ? own + (size_t)w * 64u : nxt + (size_t)(w - JD_SEG_WORDS) * 64u;
-        return *p;
+        const uint32_t *p = w < JD_SEG_WORDS ? own : nxt;
+        return p[((w & (JD_SEG_WORDS - 1u)) >> 2) * 256u + (w & 3u)];
     }
     __device__ __forceinline__ void init(uint32_t p) {
         uint32_t w = p >> 5;

@@ -238,7 +238,7 @@ void jd_plan_unstuff_host(jd_plan *P) {
         uint8_t *dst = P->clean + im->clean_off;
         for (uint32_t s = 0; s < im->n_segs; ++s)
             for (uint32_t o = 0; o < JD_SEG_BYTES; ++o)
-                dst[(((size_t)(s >> 6) * JD_SEG_WORDS + (o >> 2)) * 64u + (s & 63u)) * 4u + (o & 3u)] = lin[(size_t)s * JD_SEG_BYTES + o];
+                dst[(((size_t)(s >> 6) * (JD_SEG_BYTES / 16u) + (o >> 4)) * 64u + (s & 63u)) * 16u + (o & 15u)] = lin[(size_t)s * JD_SEG_BYTES + o];
         free(lin);
     }
 }
