@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
  * ========================================================================================== */
 
 struct SegTables {
-    const jd_lut *lut;      /* LDS copy of the image's JD_LUT_SLOTS tables */
+    const jd_lut_hot *lut;  /* LDS copy of the lookup part of the image's JD_LUT_SLOTS tables */
+    const jd_lut *glut;     /* the whole tables in global memory (canonical fallback) */
     const uint16_t *blk;    /* LDS: per data unit of the MCU: dc slot | ac slot << 4 | comp << 8 */
     uint32_t bpm;
 };
@@ -424,8 +425,8 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     while (p < valid) {
         uint32_t top = R.top();
         bool isdc = (k == 0);
-        const jd_lut *t = T.lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
-        SymInfo s = lookup(t, top >> 16);
+        const uint32_t slot = isdc ? (tb & 15u) : ((tb >> 4) & 15u);
+        SymInfo s = lookup(T.lut + slot, T.glut + slot, top >> 16);
         bad |= s.bad;
         uint32_t tot = s.len + s.size;
         if (isdc) {
@@ -453,10 +454,12 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     return r;
 }
 
-__device__ __forceinline__ void stage_tables(jd_lut *s_lut, uint16_t *s_blk, const jd_lut *g_lut, const jd_image &im) {
+__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, uint16_t *s_blk, const jd_lut *g_lut, const jd_image &im) {
+    constexpr uint32_t HOT16 = sizeof(jd_lut_hot) / 16, LUT16 = sizeof(jd_lut) / 16;
     const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-    for (uint32_t i = threadIdx.x; i < JD_LUT_SLOTS * sizeof(jd_lut) / 16; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < JD_LUT_SLOTS * HOT16; i += blockDim.x)
+        dst[i] = src[(i / HOT16) * LUT16 + i % HOT16];
     if (threadIdx.x < JD_MAX_BPM)
         s_blk[threadIdx.x] = (uint16_t)(im.blk_dc[threadIdx.x] | (im.blk_ac[threadIdx.x] << 4) | (im.blk_comp[threadIdx.x] << 8));
 }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
                                                           const uint32_t *__restrict__ wg_exit_in,
                                                           uint32_t *__restrict__ wg_exit_out,
                                                           uint32_t *__restrict__ changed) {
-    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ uint16_t s_blk[16];
     __shared__ uint32_t s_exit[JD_WG_SEGS];
 
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
     }
     stage_tables(s_lut, s_blk, luts + im.lut_off, im);
     __syncthreads();
-    SegTables T{s_lut, s_blk, im.bpm};
+    SegTables T{s_lut, luts + im.lut_off, s_blk, im.bpm};
     BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
 
     LightResult r; r.exit_state = ex0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
                                                            int16_t *__restrict__ coef,
                                                            uint32_t *__restrict__ status) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
-    __shared__ __attribute__((aligned(16))) jd_lut s_lut[JD_LUT_SLOTS];
+    __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[JD_WWG_SEGS * WBUF_BYTES];
     __shared__ uint32_t s_qblk[JD_WWG_SEGS];   /* per wave: global unit index of the r-th finished unit */
     __shared__ uint8_t s_qlane[JD_WWG_SEGS];   /* per wave: lane (within the work-group) that holds it */
@@ -667,7 +670,8 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
     if (wg.seg0 >= n_segs) return;
     const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
     const uint32_t wlane = lane & 63u, wbase = lane & ~63u;
-    stage_tables(s_lut, s_blk, luts + im.lut_off, im);
+    const jd_lut *const g_lut = luts + im.lut_off;
+    stage_tables(s_lut, s_blk, g_lut, im);
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
         uint4 *z = reinterpret_cast<uint4 *>(s_buf + lane * WBUF_BYTES);
@@ -717,8 +721,8 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
         if (active) {
             uint32_t top = R.top();
             bool isdc = (k == 0);
-            const jd_lut *t = s_lut + (isdc ? (tb & 15u) : ((tb >> 4) & 15u));
-            SymInfo s = lookup(t, top >> 16);
+            const uint32_t slot = isdc ? (tb & 15u) : ((tb >> 4) & 15u);
+            SymInfo s = lookup(s_lut + slot, g_lut + slot, top >> 16);
             uint32_t tot = s.len + s.size;
             if (p + tot > avail) { flags |= JDGPU_IMG_EOF; active = false; }        /* src/bitstream.c:17 */
             else if (s.bad) { flags |= JDGPU_IMG_NOSYMBOL; active = false; }        /* src/hufftree.c:69,72 */

@@ -30,19 +30,32 @@ extern "C" {
 #define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
 
 /* flattened Huffman table: replaces the pointer-chased tree of src/hufftree.c */
-typedef struct {
-    /* primary[peek >> (16-JD_LUT_BITS)]: bits 4:0 code length (0 = longer than JD_LUT_BITS or
-     * no such code), 8:5 magnitude size, 12:9 zero run.  DC tables: size = symbol, run = 0. */
+#define JD_LUT_SUB     512u                   /* second-level entries (the Annex K tables need about 220) */
+#define JD_LUT_LINK    0x8000u
+#define JD_LUT_NOSUB   0xFFFu
+typedef struct {  /* the part the kernels keep in LDS */
+    /* primary[next 16 bits >> (16-JD_LUT_BITS)], resolved entry: bits 4:0 bits consumed by the
+     * code (1..16), 8:5 magnitude size, 12:9 zero run, 13 = no such code (the consumed length is
+     * then that of the reference's failing tree walk).  DC tables: size = symbol, run = 0.
+     * Link entry (bit 15, codes longer than JD_LUT_BITS below this prefix): 11:0 first entry in
+     * sub[], 14:12 number s of further stream bits that index it (1..6);  11:0 = JD_LUT_NOSUB:
+     * sub[] was too small for this table, use the canonical search below. */
     uint16_t primary[1u << JD_LUT_BITS];
-    /* codes of length 11..16, canonical: with v = next 16 bits, the length is the first L
-     * with v < limit[L-11]; symbol = symbols[(v >> (16-L)) + offset[L-11]] */
+    uint16_t sub[JD_LUT_SUB];
+} jd_lut_hot; /* 3072 B */
+typedef struct {
+    jd_lut_hot hot;
+    /* canonical description of the codes of length 11..16: with v = next 16 bits, the length is
+     * the first L with v < limit[L-11]; symbol = symbols[(v >> (16-L)) + offset[L-11]].  The
+     * host builds sub[] from it; the kernels fall back to it for JD_LUT_NOSUB links only. */
     uint32_t limit[6];
     int32_t  offset[6];
     uint8_t  symbols[256];
     uint32_t is_dc;
     uint32_t short_limit; /* 16-bit left-justified end of the codes of <= JD_LUT_BITS bits */
-    uint32_t pad[2];
-} jd_lut; /* 2048 + 24 + 24 + 256 + 16 = 2368 B, multiple of 16 */
+    uint32_t n_sub;       /* entries of sub[] in use */
+    uint32_t pad;
+} jd_lut; /* 3072 + 24 + 24 + 256 + 16 = 3392 B, multiple of 16 */
 
 /* one lookup on the next 16 bits of the stream; shared by the kernels and the host test hook */
 #ifdef __HIPCC__
@@ -51,32 +64,43 @@ typedef struct {
 #define JD_HD static inline
 #endif
 typedef struct { uint32_t len, size, run, bad; } jd_sym;
-JD_HD jd_sym jd_lut_lookup(const jd_lut *t, uint32_t v16) {
+
+/* codes longer than JD_LUT_BITS, and prefixes no code has, from the canonical ranges */
+JD_HD jd_sym jd_lut_lookup_canon(const jd_lut *t, uint32_t v16) {
     jd_sym s;
-    uint32_t e = t->primary[v16 >> (16 - JD_LUT_BITS)];
-    s.len = e & 31u; s.size = (e >> 5) & 15u; s.run = (e >> 9) & 15u; s.bad = 0;
-    if (__builtin_expect(s.len == 0, 0)) {
-        /* 11..16-bit codes: canonical ranges, the first limit above v16 gives the length */
-        uint32_t L = JD_LUT_BITS + 1;
-        for (int i = 0; i < 6; ++i) L += (v16 >= t->limit[i]) ? 1u : 0u;
-        if (L > 16 || v16 < t->short_limit) {
-            /* no code has this prefix: the reference's "Could not find next symbol in huffnode."
-             * (src/hufftree.c:69,72).  Its bitwise walk stops at the first missing child, i.e.
-             * at the first bit where v16 exceeds the last assigned code (limit[5] - 1, canonical
-             * codes fill the code space from 0 upwards): that many bits are consumed, which is
-             * what decides between this failure and end-of-data.  Speculative lanes just need
-             * to make progress. */
-            uint32_t lim = t->limit[5];
-            uint32_t diff = (v16 ^ (lim - 1u)) & 0xFFFFu;
-            s.len = (lim == 0 || L <= 16) ? (lim == 0 ? 1u : 16u) : (uint32_t)__builtin_clz(diff | 1u) - 15u;
-            s.size = 0; s.run = 0; s.bad = 1;
-        } else {
-            uint32_t idx = (uint32_t)((int32_t)(v16 >> (16 - L)) + t->offset[L - JD_LUT_BITS - 1]) & 255u;
-            uint32_t sym = t->symbols[idx];
-            s.len = L; s.size = sym & 15u;
-            if (t->is_dc) { s.run = 0; s.bad = sym > 15u; } else { s.run = sym >> 4; }
-        }
+    uint32_t L = JD_LUT_BITS + 1;
+    for (int i = 0; i < 6; ++i) L += (v16 >= t->limit[i]) ? 1u : 0u;
+    if (L > 16 || v16 < t->short_limit) {
+        /* no code has this prefix: the reference's "Could not find next symbol in huffnode."
+         * (src/hufftree.c:69,72).  Its bitwise walk stops at the first missing child, i.e.
+         * at the first bit where v16 exceeds the last assigned code (limit[5] - 1, canonical
+         * codes fill the code space from 0 upwards): that many bits are consumed, which is
+         * what decides between this failure and end-of-data.  Speculative lanes just need
+         * to make progress. */
+        uint32_t lim = t->limit[5];
+        uint32_t diff = (v16 ^ (lim - 1u)) & 0xFFFFu;
+        s.len = (lim == 0 || L <= 16) ? (lim == 0 ? 1u : 16u) : (uint32_t)__builtin_clz(diff | 1u) - 15u;
+        s.size = 0; s.run = 0; s.bad = 1;
+    } else {
+        uint32_t idx = (uint32_t)((int32_t)(v16 >> (16 - L)) + t->offset[L - JD_LUT_BITS - 1]) & 255u;
+        uint32_t sym = t->symbols[idx];
+        s.len = L; s.size = sym & 15u; s.bad = 0;
+        if (t->is_dc) { s.run = 0; s.bad = sym > 15u; } else { s.run = sym >> 4; }
     }
+    return s;
+}
+
+/* h: the table's hot part (the kernels pass their LDS copy), t: the whole table */
+JD_HD jd_sym jd_lut_lookup(const jd_lut_hot *h, const jd_lut *t, uint32_t v16) {
+    jd_sym s;
+    uint32_t e = h->primary[v16 >> (16 - JD_LUT_BITS)];
+    if (__builtin_expect((e & JD_LUT_LINK) != 0, 0)) {
+        const uint32_t first = e & 0xFFFu;
+        if (__builtin_expect(first == JD_LUT_NOSUB, 0)) return jd_lut_lookup_canon(t, v16);
+        const uint32_t rest = v16 & ((1u << (16 - JD_LUT_BITS)) - 1u);
+        e = h->sub[first + (rest >> ((16 - JD_LUT_BITS) - ((e >> 12) & 7u)))];
+    }
+    s.len = e & 31u; s.size = (e >> 5) & 15u; s.run = (e >> 9) & 15u; s.bad = (e >> 13) & 1u;
     return s;
 }
 

@@ -53,12 +53,38 @@ int jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut) {
             if (code >= (1u << L)) return -1; /* over-subscribed table */
             unsigned sym = spec->symbols[k];
             unsigned size = is_dc ? sym : (sym & 15u), run = is_dc ? 0u : (sym >> 4);
-            if (is_dc && sym > 15) continue; /* no such magnitude category: leave invalid */
             uint16_t e = (uint16_t)(L | (size << 5) | (run << 9));
+            if (is_dc && sym > 15) e = (uint16_t)(L | 0x2000u); /* no such magnitude category */
             uint32_t lo = code << (PB - L), n = 1u << (PB - L);
-            for (uint32_t j = 0; j < n; ++j) lut->primary[lo + j] = e;
+            for (uint32_t j = 0; j < n; ++j) lut->hot.primary[lo + j] = e;
         }
         code <<= 1;
+    }
+    /* second level: every prefix the short codes leave open is resolved from the canonical
+     * description, over all its 2^(16-PB) continuations, into the smallest table that is exact */
+    const unsigned RB = 16 - PB, RN = 1u << RB;
+    int overflow = 0;
+    for (uint32_t p = 0; p < (1u << PB); ++p) {
+        if (lut->hot.primary[p]) continue;
+        uint16_t e[64];
+        for (uint32_t x = 0; x < RN; ++x) {
+            jd_sym s = jd_lut_lookup_canon(lut, (p << RB) | x);
+            e[x] = (uint16_t)(s.len | (s.size << 5) | (s.run << 9) | (s.bad ? 0x2000u : 0u));
+        }
+        unsigned sb = 0; /* fewest further bits that decide the entry */
+        for (; sb < RB; ++sb) {
+            int same = 1;
+            for (uint32_t x = 0; x < RN && same; ++x) same = e[x] == e[x & ~((RN >> sb) - 1u)];
+            if (same) break;
+        }
+        if (sb == 0) { lut->hot.primary[p] = e[0]; continue; }
+        if (overflow || lut->n_sub + (1u << sb) > JD_LUT_SUB) {
+            overflow = 1;
+            lut->hot.primary[p] = (uint16_t)(JD_LUT_LINK | JD_LUT_NOSUB);
+            continue;
+        }
+        lut->hot.primary[p] = (uint16_t)(JD_LUT_LINK | (sb << 12) | lut->n_sub);
+        for (uint32_t j = 0; j < (1u << sb); ++j) lut->hot.sub[lut->n_sub++] = e[j << (RB - sb)];
     }
     return 0;
 }
@@ -249,7 +275,7 @@ int jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, 
                           unsigned *run, unsigned *size) {
     jd_lut lut;
     if (jd_lut_build(spec, is_dc, &lut)) return -2;
-    jd_sym s = jd_lut_lookup(&lut, v16 & 0xFFFFu);
+    jd_sym s = jd_lut_lookup(&lut.hot, &lut, v16 & 0xFFFFu);
     *len = s.len; *run = s.run; *size = s.size;
     return s.bad ? -1 : 0;
 }
