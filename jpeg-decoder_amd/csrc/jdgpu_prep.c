@@ -171,6 +171,11 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         im->n_intervals = ri ? (nmcu + ri - 1) / ri : 1;
         im->raw_len = (uint32_t)d->scan_len;
         im->seg_cap = (uint32_t)((d->scan_len + JD_SEG_BYTES - 1) / JD_SEG_BYTES) + im->n_intervals;
+        if ((uint64_t)((im->seg_cap + 63) / 64) * 64 * JD_SEG_BYTES >= 0xFFFFF000ull) {
+            /* the bit readers address an image's clean stream with 32-bit byte offsets */
+            im->ncomp = 0; im->n_blocks = 0; im->n_intervals = 0; im->seg_cap = 0; im->raw_len = 0;
+            continue;
+        }
         raw += align_up(d->scan_len + 16, 16);
         clean += (size_t)((im->seg_cap + 63) / 64) * 64 * JD_SEG_BYTES; /* whole 64-segment groups */
         im->u_off = nu; im->chunk_off = nr;
