@@ -531,7 +531,10 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
                                                           uint32_t *__restrict__ changed) {
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
-    __shared__ uint32_t s_exit[JD_WG_SEGS];
+    __shared__ uint32_t s_in[JD_WG_SEGS];    /* per segment of the work-group: start state of its latest decode */
+    __shared__ uint32_t s_exit[JD_WG_SEGS];  /* ... and the exit state that decode reached */
+    __shared__ uint8_t s_list[JD_WG_SEGS];   /* segments to decode again, compacted */
+    __shared__ uint32_t s_wcnt[JD_WG_SEGS / 64];
 
     const jd_huff_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
@@ -547,45 +550,82 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
     const bool first = (si & JD_SEG_FIRST) != 0;
     const uint32_t valid = si & SEG_MASK;
     const uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
+    /* what segment 0 of this work-group starts from when it does not start a restart interval */
+    const uint32_t chain_in = (RESYNC && wg.seg0 != 0) ? wg_exit_in[blockIdx.x - 1] : 0u;
 
     uint32_t in = 0; /* the guess == the true start state of a restart interval */
-    uint32_t ex0 = 0;
-    bool ch = active;
-    uint32_t nin = 0;
+    uint32_t ex = 0;
     if (RESYNC) {
         in = active ? st_in[gs] : 0u;
-        ex0 = active ? st_exit[gs] : 0u;
-        /* work-group 0 of an image starts an interval; the others chain to their predecessor */
-        nin = (first || wg.seg0 == 0 || lane != 0) ? in : wg_exit_in[blockIdx.x - 1];
-        ch = active && nin != in;
+        ex = active ? (st_exit[gs] & ~JD_ST_BAD) : 0u;
+        const bool ch = active && lane == 0 && !first && wg.seg0 != 0 && chain_in != in;
         if (!__syncthreads_or(ch)) {
-            if (lane == last) wg_exit_out[blockIdx.x] = ex0 & ~JD_ST_BAD;
+            if (lane == last) wg_exit_out[blockIdx.x] = ex;
             return;
         }
     }
+    const uint32_t ex0 = ex;
     stage_tables(s_lut, s_blk, luts + im.lut_off, im, 1);
     __syncthreads();
-    SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
-    BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
+    const uint8_t *const cimg = clean + im.clean_off;
 
-    LightResult r; r.exit_state = ex0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
-    bool dirty = false;
-    for (uint32_t round = 0; round <= JD_WG_SEGS + 1; ++round) {
-        if (ch) { in = nin; r = decode_light(R, T, in, valid); dirty = true; }
+    if (!RESYNC) {
+        /* round 1: every segment from the guess; round 2: from the predecessor's exit */
+        LightResult r; r.exit_state = 0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
+        const BitReader R = make_reader(cimg, active ? seg : wg.seg0, n_segs);
+        if (active) r = decode_light(R, T, 0u, valid);
         s_exit[lane] = r.exit_state & ~JD_ST_BAD;
         __syncthreads();
-        nin = (first || lane == 0) ? in : s_exit[lane - 1];
-        ch = active && nin != in;
-        if (!__syncthreads_or(ch)) break;
+        const uint32_t nin = (first || lane == 0) ? 0u : s_exit[lane - 1];
+        if (active && nin != 0u) { in = nin; r = decode_light(R, T, in, valid); }
+        if (active) {
+            st_in[gs] = in;
+            st_exit[gs] = r.exit_state;
+            cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+        }
+        ex = r.exit_state & ~JD_ST_BAD;
+        __syncthreads(); /* s_exit of round 1 has been read by everyone */
     }
-    if (dirty) {
-        st_in[gs] = in;
-        st_exit[gs] = r.exit_state;
-        cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+    s_in[lane] = in;
+    s_exit[lane] = ex;
+    __syncthreads();
+
+    /* further rounds: the few segments whose start state moved are decoded again, packed into
+     * the first lanes of the work-group (a wave steps through a whole segment whether one lane
+     * or all 64 have work) */
+    const uint32_t wlane = lane & 63u, wave = lane >> 6;
+    for (uint32_t round = 0; round <= JD_WG_SEGS + 1; ++round) {
+        const uint32_t nin = (!active || first) ? s_in[lane] : (lane == 0 ? ((RESYNC && wg.seg0 != 0) ? chain_in : s_in[0]) : s_exit[lane - 1]);
+        const bool ch = active && nin != s_in[lane];
+        const uint64_t bm = __ballot(ch);
+        if (wlane == 0) s_wcnt[wave] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < JD_WG_SEGS / 64; ++w) { base += w < wave ? s_wcnt[w] : 0u; total += s_wcnt[w]; }
+        if (total == 0) break;
+        if (ch) s_list[base + (uint32_t)__popcll(bm & ((1ull << wlane) - 1ull))] = (uint8_t)lane;
+        __syncthreads();
+        uint32_t j = 0, nj = 0, xj = 0;
+        if (lane < total) {
+            j = s_list[lane];
+            const uint32_t sj = wg.seg0 + j, gj = im.seg_off + sj;
+            nj = (j == 0) ? chain_in : s_exit[j - 1];
+            const LightResult r = decode_light(make_reader(cimg, sj, n_segs), T, nj, seg_info[gj] & SEG_MASK);
+            st_in[gj] = nj;
+            st_exit[gj] = r.exit_state;
+            cnt[gj] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+            xj = r.exit_state & ~JD_ST_BAD;
+        }
+        __syncthreads(); /* every s_exit[j - 1] above is read before any is replaced */
+        if (lane < total) { s_in[j] = nj; s_exit[j] = xj; }
+        __syncthreads();
     }
     if (lane == last) {
-        wg_exit_out[blockIdx.x] = r.exit_state & ~JD_ST_BAD;
-        if (RESYNC && dirty && ((r.exit_state ^ ex0) & ~JD_ST_BAD)) atomicAdd(changed, 1u);
+        const uint32_t x = s_exit[last];
+        wg_exit_out[blockIdx.x] = x;
+        if (RESYNC && x != ex0) atomicAdd(changed, 1u);
     }
 }
 

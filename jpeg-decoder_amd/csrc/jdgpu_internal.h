@@ -30,7 +30,7 @@ extern "C" {
 #define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
 
 /* flattened Huffman table: replaces the pointer-chased tree of src/hufftree.c */
-#define JD_LUT_SUB     512u                   /* second-level entries (the Annex K tables need about 220) */
+#define JD_LUT_SUB     384u                   /* second-level entries (the Annex K tables need about 220) */
 #define JD_LUT_LINK    0x8000u
 #define JD_LUT_NOSUB   0xFFFu
 typedef struct {  /* the part the kernels keep in LDS */
@@ -42,7 +42,7 @@ typedef struct {  /* the part the kernels keep in LDS */
      * sub[] was too small for this table, use the canonical search below. */
     uint16_t primary[1u << JD_LUT_BITS];
     uint16_t sub[JD_LUT_SUB];
-} jd_lut_hot; /* 3072 B */
+} jd_lut_hot; /* 2816 B */
 typedef struct {
     jd_lut_hot hot;
     /* canonical description of the codes of length 11..16: with v = next 16 bits, the length is
@@ -55,7 +55,7 @@ typedef struct {
     uint32_t short_limit; /* 16-bit left-justified end of the codes of <= JD_LUT_BITS bits */
     uint32_t n_sub;       /* entries of sub[] in use */
     uint32_t pad;
-} jd_lut; /* 3072 + 24 + 24 + 256 + 16 = 3392 B, multiple of 16 */
+} jd_lut; /* 2816 + 24 + 24 + 256 + 16 = 3136 B, multiple of 16 */
 
 /* one lookup on the next 16 bits of the stream; shared by the kernels and the host test hook */
 #ifdef __HIPCC__
