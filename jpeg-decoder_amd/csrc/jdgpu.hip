@@ -447,43 +447,96 @@ __device__ __forceinline__ BitReader make_reader(const uint8_t *clean_img, uint3
 
 struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
 
+/* checkpoints inside a segment: at the first symbol boundary at or after bit (c+1) * JD_CP_BITS
+ * a light decode records its state (cp_state) and what it counted since the previous checkpoint
+ * (cp_val; entry JD_CP: from the last checkpoint to the end).  A later decode of the same segment
+ * from another start state that arrives at a checkpoint in the recorded state is from there on
+ * identical to the recorded one: it stops and adds up the recorded rest. */
+#ifndef JD_CP
+#define JD_CP       3u
+#endif
+#define JD_CP_BITS  (JD_SEG_BITS / (JD_CP + 1u))
+#define JD_CP_NONE  0xFFFFFFFFu
+
 /*
  * Light decode (no coefficient output): from packed start state `in` run to the end of the
  * segment's valid bits; report the exit state, the number of data units COMPLETED and the sum
- * of DC differences seen per component.
+ * of DC differences seen per component.  COMPARE: stop early at a checkpoint that matches the
+ * recorded decode (whose exit state is old_exit).
  */
-__device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables &T, uint32_t in, uint32_t valid) {
+template <bool COMPARE>
+__device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables &T, uint32_t in, uint32_t valid,
+                                                    uint32_t *__restrict__ cp_state, int4 *__restrict__ cp_val,
+                                                    uint32_t old_exit) {
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
     uint32_t bad = 0;
-    int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;      /* since the last checkpoint */
+    int tn = 0, t0 = 0, t1 = 0, t2 = 0;        /* up to the last checkpoint */
+    uint32_t old[JD_CP];
+#pragma unroll
+    for (uint32_t c = 0; c < JD_CP; ++c) old[c] = COMPARE ? cp_state[c] : JD_CP_NONE;
+    bool matched = false;
     R.init(p);
     BlkDesc tb = T.blk[b];
-    while (p < valid) {
-        const uint32_t top = R.top();
-        const bool isdc = (k == 0);
-        const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
-        const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
-        bad |= e;
-        /* DC difference (0 for AC symbols), added to the sum of the unit's component */
-        int d = extend_top(top << len, size);
-        d = isdc ? d : 0;
-        dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
-        /* src/decoding.c:53-63: i += run; size 0: run 15 -> skip 16, else end of block */
-        k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
-        const uint32_t tot = len + size;
-        p += tot;
-        R.consume(tot); /* measured against advance() + prefetch() here: 6.2 vs 6.8 ms per 2048 images */
-        /* end of the data unit, branch-free; the descriptor is re-read in every step so that no
-         * divergent merge copies it around */
-        const bool end = k >= 64u;
-        const uint32_t nb = (b + 1 == T.bpm) ? 0 : b + 1;
-        k = end ? 0u : k; n += end ? 1 : 0; b = end ? nb : b;
-        tb = T.blk[b];
+#pragma unroll
+    for (uint32_t c = 0; c <= JD_CP; ++c) {
+        const uint32_t mark = (c + 1u) * JD_CP_BITS;
+        const uint32_t lim = c < JD_CP ? min(valid, mark) : valid;
+        while (p < lim) {
+            const uint32_t top = R.top();
+            const bool isdc = (k == 0);
+            const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
+            const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
+            bad |= e;
+            /* DC difference (0 for AC symbols), added to the sum of the unit's component */
+            int d = extend_top(top << len, size);
+            d = isdc ? d : 0;
+            dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
+            /* src/decoding.c:53-63: i += run; size 0: run 15 -> skip 16, else end of block */
+            k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
+            const uint32_t tot = len + size;
+            p += tot;
+            R.consume(tot); /* measured against advance() + prefetch() here: 6.2 vs 6.8 ms per 2048 images */
+            /* end of the data unit, branch-free; the descriptor is re-read in every step so that
+             * no divergent merge copies it around */
+            const bool end = k >= 64u;
+            const uint32_t nb = (b + 1 == T.bpm) ? 0 : b + 1;
+            k = end ? 0u : k; n += end ? 1 : 0; b = end ? nb : b;
+            tb = T.blk[b];
+        }
+        if (c < JD_CP && !matched) {
+            if (p >= mark) {
+                const uint32_t st = p | (k << 13) | (b << 20);
+                tn += n; t0 += dc0; t1 += dc1; t2 += dc2;
+                cp_val[c] = make_int4(n, dc0, dc1, dc2); /* also on a match: the way here was new */
+                if (COMPARE && st == old[c]) {
+#pragma unroll
+                    for (uint32_t i = c + 1; i <= JD_CP; ++i) {
+                        const int4 v = cp_val[i];
+                        tn += v.x; t0 += v.y; t1 += v.z; t2 += v.w;
+                    }
+                    matched = true;
+                    p = 0xFFFFFFFFu; /* no further step */
+                } else {
+                    cp_state[c] = st;
+                }
+                n = dc0 = dc1 = dc2 = 0;
+            } else { /* the segment ends before this checkpoint */
+                cp_state[c] = JD_CP_NONE;
+                cp_val[c] = make_int4(0, 0, 0, 0);
+            }
+        }
     }
     LightResult r;
-    uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
-    r.exit_state = JD_ST_PACK(ovs, k, b) | ((bad & 0x2000u) ? JD_ST_BAD : 0u);
-    r.n = n; r.dc0 = dc0; r.dc1 = dc1; r.dc2 = dc2;
+    if (matched) {
+        r.exit_state = old_exit;
+    } else {
+        cp_val[JD_CP] = make_int4(n, dc0, dc1, dc2);
+        tn += n; t0 += dc0; t1 += dc1; t2 += dc2;
+        const uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
+        r.exit_state = JD_ST_PACK(ovs, k, b) | ((bad & 0x2000u) ? JD_ST_BAD : 0u);
+    }
+    r.n = tn; r.dc0 = t0; r.dc1 = t1; r.dc2 = t2;
     return r;
 }
 
@@ -528,7 +581,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
                                                           int4 *__restrict__ cnt,
                                                           const uint32_t *__restrict__ wg_exit_in,
                                                           uint32_t *__restrict__ wg_exit_out,
-                                                          uint32_t *__restrict__ changed) {
+                                                          uint32_t *__restrict__ changed,
+                                                          uint32_t *__restrict__ cp_state,
+                                                          int4 *__restrict__ cp_val) {
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
     __shared__ uint32_t s_in[JD_WG_SEGS];    /* per segment of the work-group: start state of its latest decode */
@@ -574,11 +629,13 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
         /* round 1: every segment from the guess; round 2: from the predecessor's exit */
         LightResult r; r.exit_state = 0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
         const BitReader R = make_reader(cimg, active ? seg : wg.seg0, n_segs);
-        if (active) r = decode_light(R, T, 0u, valid);
+        uint32_t *const cps = cp_state + (size_t)gs * JD_CP;
+        int4 *const cpv = cp_val + (size_t)gs * (JD_CP + 1u);
+        if (active) r = decode_light<false>(R, T, 0u, valid, cps, cpv, 0u);
         s_exit[lane] = r.exit_state & ~JD_ST_BAD;
         __syncthreads();
         const uint32_t nin = (first || lane == 0) ? 0u : s_exit[lane - 1];
-        if (active && nin != 0u) { in = nin; r = decode_light(R, T, in, valid); }
+        if (active && nin != 0u) { in = nin; r = decode_light<true>(R, T, in, valid, cps, cpv, r.exit_state); }
         if (active) {
             st_in[gs] = in;
             st_exit[gs] = r.exit_state;
@@ -612,7 +669,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
             j = s_list[lane];
             const uint32_t sj = wg.seg0 + j, gj = im.seg_off + sj;
             nj = (j == 0) ? chain_in : s_exit[j - 1];
-            const LightResult r = decode_light(make_reader(cimg, sj, n_segs), T, nj, seg_info[gj] & SEG_MASK);
+            const LightResult r = decode_light<true>(make_reader(cimg, sj, n_segs), T, nj, seg_info[gj] & SEG_MASK,
+                                                     cp_state + (size_t)gj * JD_CP, cp_val + (size_t)gj * (JD_CP + 1u),
+                                                     s_exit[j]);
             st_in[gj] = nj;
             st_exit[gj] = r.exit_state;
             cnt[gj] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
@@ -1181,8 +1240,8 @@ struct jdgpu_batch {
     uint8_t *d_raw, *d_clean, *d_pix;
     jd_image *d_img;
     jd_lut *d_luts;
-    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_wg_exit[2], *d_status, *d_changed;
-    int4 *d_cnt, *d_start_dc;
+    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_wg_exit[2], *d_status, *d_changed, *d_cp_state;
+    int4 *d_cnt, *d_start_dc, *d_cp_val;
     int2 *d_start_blk;
     int16_t *d_coef;
     jd_huff_wg *d_hwg, *d_wwg;
@@ -1254,7 +1313,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_raw); hipFree(b->d_clean); hipFree(b->d_pix); hipFree(b->d_img); hipFree(b->d_luts);
     hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_wg_exit[0]);
-    hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt);
+    hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt); hipFree(b->d_cp_state); hipFree(b->d_cp_val);
     hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
     hipFree(b->d_rwg); hipFree(b->d_wwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
     if (b->h_changed) hipHostFree(b->h_changed);
@@ -1275,6 +1334,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->stream = nullptr; b->h_changed = nullptr; b->retries = 0; b->timed = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_wg_exit[0] = b->d_wg_exit[1] = b->d_status = b->d_changed = nullptr;
+    b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
     b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
     for (auto &e : b->ev) e = nullptr;
@@ -1295,6 +1355,8 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_st_in, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_st_exit, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_cnt, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_cp_state, (size_t)P.n_segs_cap * JD_CP));
+    TRY(dalloc(&b->d_cp_val, (size_t)P.n_segs_cap * (JD_CP + 1u)));
     TRY(dalloc(&b->d_start_dc, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_start_blk, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_wg_exit[0], (size_t)P.n_hwg));
@@ -1337,13 +1399,13 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     if (first_pass) {
         hipLaunchKernelGGL(k_huff_sync<false>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
                            b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[1], b->d_wg_exit[0],
-                           b->d_changed);
+                           b->d_changed, b->d_cp_state, b->d_cp_val);
     }
     /* one stitching round across work-groups (more only if k_huff_write reports UNSYNCED) */
     int src = first_pass ? 0 : (b->retries & 1);
     hipLaunchKernelGGL(k_huff_sync<true>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
                        b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[src],
-                       b->d_wg_exit[src ^ 1], b->d_changed);
+                       b->d_wg_exit[src ^ 1], b->d_changed, b->d_cp_state, b->d_cp_val);
     return JDGPU_OK;
 }
 
