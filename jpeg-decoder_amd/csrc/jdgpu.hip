@@ -540,6 +540,33 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     return r;
 }
 
+/* state-only decode: from bit p0 of the reader's segment, expecting a DC symbol of data unit 0,
+ * to the end of the segment; returns the packed state reached (no counting).  Used to guess the
+ * start state of the NEXT segment from the last JD_OVERLAP bits of this one. */
+#ifndef JD_OVERLAP
+#define JD_OVERLAP 1024u
+#endif
+__device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTables &T, uint32_t p0, uint32_t valid) {
+    uint32_t p = p0, k = 0, b = 0;
+    R.init(p);
+    BlkDesc tb = T.blk[b];
+    while (p < valid) {
+        const uint32_t top = R.top();
+        const bool isdc = (k == 0);
+        const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
+        const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
+        k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
+        const uint32_t tot = len + size;
+        p += tot;
+        R.consume(tot);
+        const bool end = k >= 64u;
+        const uint32_t nb = (b + 1 == T.bpm) ? 0 : b + 1;
+        k = end ? 0u : k; b = end ? nb : b;
+        tb = T.blk[b];
+    }
+    return JD_ST_PACK(p - valid, k, b);
+}
+
 __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im, int sel) {
     constexpr uint32_t HOT16 = sizeof(jd_lut_hot) / 16, LUT16 = sizeof(jd_lut) / 16;
     const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
@@ -626,23 +653,22 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
     const uint8_t *const cimg = clean + im.clean_off;
 
     if (!RESYNC) {
-        /* round 1: every segment from the guess; round 2: from the predecessor's exit */
-        LightResult r; r.exit_state = 0; r.n = r.dc0 = r.dc1 = r.dc2 = 0;
-        const BitReader R = make_reader(cimg, active ? seg : wg.seg0, n_segs);
-        uint32_t *const cps = cp_state + (size_t)gs * JD_CP;
-        int4 *const cpv = cp_val + (size_t)gs * (JD_CP + 1u);
-        if (active) r = decode_light<false>(R, T, 0u, valid, cps, cpv, 0u);
-        s_exit[lane] = r.exit_state & ~JD_ST_BAD;
-        __syncthreads();
-        const uint32_t nin = (first || lane == 0) ? 0u : s_exit[lane - 1];
-        if (active && nin != 0u) { in = nin; r = decode_light<true>(R, T, in, valid, cps, cpv, r.exit_state); }
+        /* start state of every segment that does not start an interval: guessed by decoding the
+         * last JD_OVERLAP bits of its predecessor from "expecting DC, data unit 0" (JPEG Huffman
+         * streams self-synchronise); then the segment itself from that state.  Wrong guesses show
+         * as breaks in the chain of states and are repaired below. */
+        if (active && !first) {
+            const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
+            in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
+        }
         if (active) {
+            const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, valid,
+                                                      cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
             st_in[gs] = in;
             st_exit[gs] = r.exit_state;
             cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+            ex = r.exit_state & ~JD_ST_BAD;
         }
-        ex = r.exit_state & ~JD_ST_BAD;
-        __syncthreads(); /* s_exit of round 1 has been read by everyone */
     }
     s_in[lane] = in;
     s_exit[lane] = ex;
@@ -662,6 +688,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
 #pragma unroll
         for (uint32_t w = 0; w < JD_WG_SEGS / 64; ++w) { base += w < wave ? s_wcnt[w] : 0u; total += s_wcnt[w]; }
         if (total == 0) break;
+#ifdef JD_STATS
+        if (lane == 0) { atomicAdd(changed + 1, 1u); atomicAdd(changed + 2, total); }
+#endif
         if (ch) s_list[base + (uint32_t)__popcll(bm & ((1ull << wlane) - 1ull))] = (uint8_t)lane;
         __syncthreads();
         uint32_t j = 0, nj = 0, xj = 0;
@@ -676,6 +705,9 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__rest
             st_exit[gj] = r.exit_state;
             cnt[gj] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
             xj = r.exit_state & ~JD_ST_BAD;
+#ifdef JD_STATS
+            if (xj == s_exit[j]) atomicAdd(changed + 3, 1u);
+#endif
         }
         __syncthreads(); /* every s_exit[j - 1] above is read before any is replaced */
         if (lane < total) { s_in[j] = nj; s_exit[j] = xj; }
@@ -1497,6 +1529,11 @@ extern "C" uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b) {
 }
 extern "C" size_t jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i) { return (b && i < b->plan.n) ? b->plan.img[i].n_blocks : 0; }
 extern "C" int jdgpu_batch_retries(const jdgpu_batch *b) { return b ? b->retries : 0; }
+#ifdef JD_STATS
+extern "C" int jdgpu_batch_debug_counters(jdgpu_batch *b, uint32_t out[16]) {
+    return hipMemcpy(out, b->d_changed, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" void *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i) {
     if (!b || i >= b->plan.n) return nullptr;
