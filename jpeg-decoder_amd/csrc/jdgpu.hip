@@ -506,7 +506,7 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
         }
         if (c < JD_CP && !matched) {
             if (p >= mark) {
-                const uint32_t st = p | (k << 13) | (b << 20);
+                const uint32_t st = p | (k << 16) | (b << 24);
                 tn += n; t0 += dc0; t1 += dc1; t2 += dc2;
                 cp_val[c] = make_int4(n, dc0, dc1, dc2); /* also on a match: the way here was new */
                 if (COMPARE && st == old[c]) {
