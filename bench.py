@@ -133,7 +133,7 @@ def main():
     for _ in range(args.warmup):
         batch.decode()
     for i in range(batch.n):
-        if batch.status(i):
+        if batch.status(i) and not os.environ.get("JD_BENCH_ABLATION"):  # ablation builds decode garbage on purpose
             raise SystemExit(f"image {i} failed to decode: status {batch.status(i)}")
     stage_sum = {}
     barrier()

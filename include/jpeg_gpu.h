@@ -125,6 +125,9 @@ int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
 int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
 /* number of extra stitching rounds the last decode needed (0 in the common case) */
 int      jdgpu_batch_retries(const jdgpu_batch *b);
+/* development aid: how many segments the start-state repair listed in each of its rounds during
+ * the last decode pass (summed over the images); rounds beyond the built-in number read 0 */
+int      jdgpu_batch_repair_counts(jdgpu_batch *b, uint32_t *out, size_t rounds);
 
 /* ---- host-side test hooks: the flattened-table lookup and the unstuff stage as plain C, so the
  *      CPU test-suite can check them against the tree walk (src/hufftree.c:64-78) and the byte

@@ -29,7 +29,7 @@ EXPORTS = [
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
-    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_ycbcr_to_rgb",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb",
     "jdgpu_host_lut_lookup", "jdgpu_host_unstuff", "jdgpu_batch_debug_segments",
     "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
@@ -94,6 +94,7 @@ def lib():
     L.jdgpu_batch_read_coefficients.argtypes = [vp, sz, vp]
     L.jdgpu_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.jdgpu_batch_retries.argtypes = [vp]
+    L.jdgpu_batch_repair_counts.argtypes = [vp, C.POINTER(C.c_uint32), sz]
     L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_host_lut_lookup.argtypes = [C.POINTER(HuffSpec), C.c_int, C.c_uint, C.POINTER(C.c_uint),
                                         C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
@@ -202,6 +203,14 @@ class Batch:
     @property
     def total_scan_bytes(self):
         return int(self._L.jdgpu_batch_total_scan_bytes(self._h))
+
+    def repair_counts(self, rounds=8):
+        """segments listed for a start-state repair in each round of the last pass"""
+        out = (C.c_uint32 * rounds)()
+        rc = self._L.jdgpu_batch_repair_counts(self._h, out, rounds)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_repair_counts", rc)
+        return list(out)
 
     @property
     def retries(self):

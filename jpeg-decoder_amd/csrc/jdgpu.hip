@@ -46,6 +46,7 @@ static thread_local char g_err[512] = "";
     } while (0)
 
 #define SEG_MASK 0xFFFFu /* valid-bit count in a per-segment word */
+#define JD_REPAIR_ROUNDS 6u /* chain check + repair launches per pass */
 
 /* The clean stream is stored transposed in groups of 64 segments, 16 bytes at a time: bytes
  * [16q, 16q+16) of segment s live at [(s / 64) * (JD_SEG_BYTES/16) + q][s % 64], so the 64 lanes
@@ -584,140 +585,128 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
 }
 
 /*
- * k_huff_sync<RESYNC = false>: speculative decode + stitching inside a work-group of
- * JD_WG_SEGS segments.  Every lane decodes its segment from the guess "bit 0, expecting DC,
- * data unit 0" (exact for the first segment of a restart interval), then keeps re-decoding from
- * its predecessor's exit state until no state in the work-group changes: JPEG Huffman streams
- * self-synchronise, so a wrong start usually turns into the right exit within one segment.
+ * Start states.  Three kernels, all one lane per segment, work-groups of JD_WG_SEGS segments of
+ * one image (they share the image's lookup tables in LDS):
  *
- * k_huff_sync<RESYNC = true>: stitch work-groups.  Lane 0 takes the exit state of the previous
- * work-group's last segment (wg_exit_in, written by the previous launch); only lanes whose
- * input changes re-decode.  *changed counts work-groups whose own last exit moved.
+ *   k_huff_first   every segment that does not start a restart interval guesses its start state
+ *                  by decoding the last JD_OVERLAP bits of its predecessor from "expecting DC,
+ *                  data unit 0" (JPEG Huffman streams self-synchronise), then decodes itself
+ *                  from that state: exit state, data units completed, DC difference sums.
+ *   k_chain_check  a segment whose start state is not its predecessor's exit state goes on the
+ *                  image's repair list.
+ *   k_huff_repair  decodes the listed segments again, packed densely into lanes, from the
+ *                  predecessor's exit state; stops early at a checkpoint the earlier decode
+ *                  passed in the same state.
+ *
+ * check + repair run a fixed number of rounds (a repaired segment seldom ends in a new state, so
+ * the lists shrink by ~50x per round); k_huff_write verifies the chain once more and the host
+ * adds rounds in the rare case that it is still broken.  Repairs are a separate launch rather
+ * than a loop inside the first kernel so that no wave sits at a barrier, holding its SIMD slot,
+ * while a few lanes of its work-group decode again (measured: 5.6 -> 3 ms per 2048 images).
  *
  * st_in / st_exit / cnt: per segment the start state used, the exit state reached, and
  * (data units completed, DC difference sums per component).
  */
-template <bool RESYNC>
-__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_sync(const jd_image *__restrict__ imgs,
-                                                          const jd_lut *__restrict__ luts,
-                                                          const uint8_t *__restrict__ clean,
-                                                          const uint32_t *__restrict__ seg_info,
-                                                          const jd_huff_wg *__restrict__ wgs,
-                                                          uint32_t *__restrict__ st_in,
-                                                          uint32_t *__restrict__ st_exit,
-                                                          int4 *__restrict__ cnt,
-                                                          const uint32_t *__restrict__ wg_exit_in,
-                                                          uint32_t *__restrict__ wg_exit_out,
-                                                          uint32_t *__restrict__ changed,
-                                                          uint32_t *__restrict__ cp_state,
-                                                          int4 *__restrict__ cp_val) {
+__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__restrict__ imgs,
+                                                           const jd_lut *__restrict__ luts,
+                                                           const uint8_t *__restrict__ clean,
+                                                           const uint32_t *__restrict__ seg_info,
+                                                           const jd_huff_wg *__restrict__ wgs,
+                                                           uint32_t *__restrict__ st_in,
+                                                           uint32_t *__restrict__ st_exit,
+                                                           int4 *__restrict__ cnt,
+                                                           uint32_t *__restrict__ cp_state,
+                                                           int4 *__restrict__ cp_val) {
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
-    __shared__ uint32_t s_in[JD_WG_SEGS];    /* per segment of the work-group: start state of its latest decode */
-    __shared__ uint32_t s_exit[JD_WG_SEGS];  /* ... and the exit state that decode reached */
-    __shared__ uint8_t s_list[JD_WG_SEGS];   /* segments to decode again, compacted */
-    __shared__ uint32_t s_wcnt[JD_WG_SEGS / 64];
 
     const jd_huff_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
-    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
-    if (wg.seg0 >= n_segs) {
-        if (lane == 0) wg_exit_out[blockIdx.x] = 0;
-        return;
-    }
-    const bool active = seg < n_segs;
-    const uint32_t gs = im.seg_off + seg;
-    const uint32_t si = active ? seg_info[gs] : JD_SEG_FIRST;
-    const bool first = (si & JD_SEG_FIRST) != 0;
-    const uint32_t valid = si & SEG_MASK;
-    const uint32_t last = min(JD_WG_SEGS, n_segs - wg.seg0) - 1;
-    /* what segment 0 of this work-group starts from when it does not start a restart interval */
-    const uint32_t chain_in = (RESYNC && wg.seg0 != 0) ? wg_exit_in[blockIdx.x - 1] : 0u;
-
-    uint32_t in = 0; /* the guess == the true start state of a restart interval */
-    uint32_t ex = 0;
-    if (RESYNC) {
-        in = active ? st_in[gs] : 0u;
-        ex = active ? (st_exit[gs] & ~JD_ST_BAD) : 0u;
-        const bool ch = active && lane == 0 && !first && wg.seg0 != 0 && chain_in != in;
-        if (!__syncthreads_or(ch)) {
-            if (lane == last) wg_exit_out[blockIdx.x] = ex;
-            return;
-        }
-    }
-    const uint32_t ex0 = ex;
+    if (wg.seg0 >= n_segs) return;
+    const uint32_t seg = wg.seg0 + threadIdx.x;
     stage_tables(s_lut, s_blk, luts + im.lut_off, im, 1);
     __syncthreads();
+    if (seg >= n_segs) return;
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
     const uint8_t *const cimg = clean + im.clean_off;
+    const uint32_t gs = im.seg_off + seg;
+    const uint32_t si = seg_info[gs];
 
-    if (!RESYNC) {
-        /* start state of every segment that does not start an interval: guessed by decoding the
-         * last JD_OVERLAP bits of its predecessor from "expecting DC, data unit 0" (JPEG Huffman
-         * streams self-synchronise); then the segment itself from that state.  Wrong guesses show
-         * as breaks in the chain of states and are repaired below. */
-        if (active && !first) {
-            const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
-            in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
-        }
-        if (active) {
-            const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, valid,
-                                                      cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
-            st_in[gs] = in;
-            st_exit[gs] = r.exit_state;
-            cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
-            ex = r.exit_state & ~JD_ST_BAD;
-        }
+    uint32_t in = 0; /* the true start state of a restart interval */
+    if (!(si & JD_SEG_FIRST)) {
+        const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
+        in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
     }
-    s_in[lane] = in;
-    s_exit[lane] = ex;
+    const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
+                                              cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
+    st_in[gs] = in;
+    st_exit[gs] = r.exit_state;
+    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+}
+
+__global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__restrict__ imgs,
+                                                            const uint32_t *__restrict__ seg_info,
+                                                            const jd_huff_wg *__restrict__ wgs,
+                                                            const uint32_t *__restrict__ st_in,
+                                                            const uint32_t *__restrict__ st_exit,
+                                                            uint32_t *__restrict__ list,
+                                                            uint32_t *__restrict__ list_cnt) {
+    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_image &im = imgs[wg.img];
+    const uint32_t seg = wg.seg0 + threadIdx.x;
+    bool broken = false;
+    if (seg < im.n_segs) {
+        const uint32_t gs = im.seg_off + seg;
+        const uint32_t want = (seg_info[gs] & JD_SEG_FIRST) ? 0u : (st_exit[gs - 1] & ~JD_ST_BAD);
+        broken = st_in[gs] != want;
+    }
+    const uint64_t bm = __ballot(broken);
+    if (bm) {
+        const uint32_t wlane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (wlane == (uint32_t)__ffsll((long long)bm) - 1u) base = atomicAdd(&list_cnt[wg.img], (uint32_t)__popcll(bm));
+        base = __shfl(base, __ffsll((long long)bm) - 1);
+        if (broken) list[im.seg_off + base + (uint32_t)__popcll(bm & ((1ull << wlane) - 1ull))] = seg;
+    }
+}
+
+__global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__restrict__ imgs,
+                                                            const jd_lut *__restrict__ luts,
+                                                            const uint8_t *__restrict__ clean,
+                                                            const uint32_t *__restrict__ seg_info,
+                                                            const jd_huff_wg *__restrict__ wgs,
+                                                            const uint32_t *__restrict__ list,
+                                                            const uint32_t *__restrict__ list_cnt,
+                                                            uint32_t *st_in,
+                                                            uint32_t *st_exit, /* read (predecessors) and written: no __restrict__ */
+                                                            int4 *__restrict__ cnt,
+                                                            uint32_t *__restrict__ cp_state,
+                                                            int4 *__restrict__ cp_val) {
+    __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
+    __shared__ BlkDesc s_blk[JD_MAX_BPM];
+
+    const jd_huff_wg wg = wgs[blockIdx.x];   /* here: entries [seg0, seg0 + JD_WG_SEGS) of the image's list */
+    const jd_image &im = imgs[wg.img];
+    const uint32_t n_list = min(list_cnt[wg.img], im.n_segs);
+    if (wg.seg0 >= n_list) return;
+    stage_tables(s_lut, s_blk, luts + im.lut_off, im, 1);
     __syncthreads();
-
-    /* further rounds: the few segments whose start state moved are decoded again, packed into
-     * the first lanes of the work-group (a wave steps through a whole segment whether one lane
-     * or all 64 have work) */
-    const uint32_t wlane = lane & 63u, wave = lane >> 6;
-    for (uint32_t round = 0; round <= JD_WG_SEGS + 1; ++round) {
-        const uint32_t nin = (!active || first) ? s_in[lane] : (lane == 0 ? ((RESYNC && wg.seg0 != 0) ? chain_in : s_in[0]) : s_exit[lane - 1]);
-        const bool ch = active && nin != s_in[lane];
-        const uint64_t bm = __ballot(ch);
-        if (wlane == 0) s_wcnt[wave] = (uint32_t)__popcll(bm);
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < JD_WG_SEGS / 64; ++w) { base += w < wave ? s_wcnt[w] : 0u; total += s_wcnt[w]; }
-        if (total == 0) break;
-#ifdef JD_STATS
-        if (lane == 0) { atomicAdd(changed + 1, 1u); atomicAdd(changed + 2, total); }
-#endif
-        if (ch) s_list[base + (uint32_t)__popcll(bm & ((1ull << wlane) - 1ull))] = (uint8_t)lane;
-        __syncthreads();
-        uint32_t j = 0, nj = 0, xj = 0;
-        if (lane < total) {
-            j = s_list[lane];
-            const uint32_t sj = wg.seg0 + j, gj = im.seg_off + sj;
-            nj = (j == 0) ? chain_in : s_exit[j - 1];
-            const LightResult r = decode_light<true>(make_reader(cimg, sj, n_segs), T, nj, seg_info[gj] & SEG_MASK,
-                                                     cp_state + (size_t)gj * JD_CP, cp_val + (size_t)gj * (JD_CP + 1u),
-                                                     s_exit[j]);
-            st_in[gj] = nj;
-            st_exit[gj] = r.exit_state;
-            cnt[gj] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
-            xj = r.exit_state & ~JD_ST_BAD;
-#ifdef JD_STATS
-            if (xj == s_exit[j]) atomicAdd(changed + 3, 1u);
-#endif
-        }
-        __syncthreads(); /* every s_exit[j - 1] above is read before any is replaced */
-        if (lane < total) { s_in[j] = nj; s_exit[j] = xj; }
-        __syncthreads();
-    }
-    if (lane == last) {
-        const uint32_t x = s_exit[last];
-        wg_exit_out[blockIdx.x] = x;
-        if (RESYNC && x != ex0) atomicAdd(changed, 1u);
-    }
+    const uint32_t idx = wg.seg0 + threadIdx.x;
+    if (idx >= n_list) return;
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
+    const uint32_t seg = list[im.seg_off + idx];
+    const uint32_t gs = im.seg_off + seg;
+    /* a listed segment never starts an interval, so it has a predecessor.  That one may be on
+     * the list too and change its exit state while this lane reads it: either value is a
+     * consistent start, and the next check lists this segment again if it was the old one. */
+    const uint32_t in = st_exit[gs - 1] & ~JD_ST_BAD;
+    const LightResult r = decode_light<true>(make_reader(clean + im.clean_off, seg, im.n_segs), T, in, seg_info[gs] & SEG_MASK,
+                                             cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u),
+                                             st_exit[gs] & ~JD_ST_BAD);
+    st_in[gs] = in;
+    st_exit[gs] = r.exit_state;
+    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
 }
 
 /* ============================================================================================
@@ -1272,7 +1261,8 @@ struct jdgpu_batch {
     uint8_t *d_raw, *d_clean, *d_pix;
     jd_image *d_img;
     jd_lut *d_luts;
-    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_wg_exit[2], *d_status, *d_changed, *d_cp_state;
+    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_status, *d_cp_state;
+    uint32_t *d_list, *d_list_cnt;   /* repair lists: [segment capacity], [JD_REPAIR_ROUNDS][images] */
     int4 *d_cnt, *d_start_dc, *d_cp_val;
     int2 *d_start_blk;
     int16_t *d_coef;
@@ -1344,8 +1334,8 @@ static int dalloc(T **p, size_t count) {
 extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_raw); hipFree(b->d_clean); hipFree(b->d_pix); hipFree(b->d_img); hipFree(b->d_luts);
-    hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_wg_exit[0]);
-    hipFree(b->d_wg_exit[1]); hipFree(b->d_status); hipFree(b->d_changed); hipFree(b->d_cnt); hipFree(b->d_cp_state); hipFree(b->d_cp_val);
+    hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_list);
+    hipFree(b->d_list_cnt); hipFree(b->d_status); hipFree(b->d_cnt); hipFree(b->d_cp_state); hipFree(b->d_cp_val);
     hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
     hipFree(b->d_rwg); hipFree(b->d_wwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
     if (b->h_changed) hipHostFree(b->h_changed);
@@ -1365,7 +1355,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->flags = flags;
     b->stream = nullptr; b->h_changed = nullptr; b->retries = 0; b->timed = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
-    b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_wg_exit[0] = b->d_wg_exit[1] = b->d_status = b->d_changed = nullptr;
+    b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
     b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
@@ -1391,10 +1381,9 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_cp_val, (size_t)P.n_segs_cap * (JD_CP + 1u)));
     TRY(dalloc(&b->d_start_dc, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_start_blk, (size_t)P.n_segs_cap));
-    TRY(dalloc(&b->d_wg_exit[0], (size_t)P.n_hwg));
-    TRY(dalloc(&b->d_wg_exit[1], (size_t)P.n_hwg));
+    TRY(dalloc(&b->d_list, (size_t)P.n_segs_cap));
+    TRY(dalloc(&b->d_list_cnt, (size_t)JD_REPAIR_ROUNDS * (n ? n : 1)));
     TRY(dalloc(&b->d_status, n));
-    TRY(dalloc(&b->d_changed, 16));
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
@@ -1428,16 +1417,20 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
 
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     jd_plan &P = b->plan;
-    if (first_pass) {
-        hipLaunchKernelGGL(k_huff_sync<false>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
-                           b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[1], b->d_wg_exit[0],
-                           b->d_changed, b->d_cp_state, b->d_cp_val);
+    hipStream_t st = b->stream;
+    const dim3 grid(P.n_hwg), block(JD_WG_SEGS);
+    if (first_pass)
+        hipLaunchKernelGGL(k_huff_first, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_hwg,
+                           b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
+    /* chain check + repair; on a later pass (k_huff_write still found a break) the same again */
+    HIPCHK(hipMemsetAsync(b->d_list_cnt, 0, (size_t)JD_REPAIR_ROUNDS * P.n * 4, st));
+    for (uint32_t r = 0; r < JD_REPAIR_ROUNDS; ++r) {
+        uint32_t *lc = b->d_list_cnt + (size_t)r * P.n;
+        hipLaunchKernelGGL(k_chain_check, grid, block, 0, st, b->d_img, b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit,
+                           b->d_list, lc);
+        hipLaunchKernelGGL(k_huff_repair, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_hwg,
+                           b->d_list, lc, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     }
-    /* one stitching round across work-groups (more only if k_huff_write reports UNSYNCED) */
-    int src = first_pass ? 0 : (b->retries & 1);
-    hipLaunchKernelGGL(k_huff_sync<true>, dim3(P.n_hwg), dim3(JD_WG_SEGS), 0, b->stream, b->d_img, b->d_luts, b->d_clean,
-                       b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_wg_exit[src],
-                       b->d_wg_exit[src ^ 1], b->d_changed, b->d_cp_state, b->d_cp_val);
     return JDGPU_OK;
 }
 
@@ -1449,7 +1442,6 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     b->retries = 0;
     hipStream_t st = b->stream;
     HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
-    HIPCHK(hipMemsetAsync(b->d_changed, 0, 64, st));
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
     if (!(b->flags & JDGPU_HOST_PREP) && P.n_rwg) {
         HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
@@ -1495,12 +1487,23 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         bool unsynced = false;
         for (size_t i = 0; i < P.n; ++i) unsynced |= (st[i] & JDGPU_IMG_UNSYNCED) != 0;
         if (!unsynced) break;
-        if (attempt > 64 + (int)P.n_hwg) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
-        /* a change crossed a whole work-group: stitch once more, then redo scan + write + pixel */
+        if (attempt > 8) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
+        /* the chain of start states was still broken after the built-in repair rounds: repeat
+         * them until a round lists nothing (every round mends at least the first break of each
+         * image, so this ends), then redo scan + write + pixel */
         ++b->retries;
         hipStream_t s = b->stream;
         HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, s));
-        enqueue_huffman(b, false);
+        std::vector<uint32_t> lc(P.n);
+        for (uint32_t pass = 0;; ++pass) {
+            if (pass > P.n_segs_cap) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
+            enqueue_huffman(b, false);
+            HIPCHK(hipMemcpyAsync(lc.data(), b->d_list_cnt + (size_t)(JD_REPAIR_ROUNDS - 1) * P.n, P.n * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            bool clean = true;
+            for (size_t i = 0; i < P.n; ++i) clean &= lc[i] == 0;
+            if (clean) break;
+        }
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
@@ -1529,11 +1532,18 @@ extern "C" uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b) {
 }
 extern "C" size_t jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i) { return (b && i < b->plan.n) ? b->plan.img[i].n_blocks : 0; }
 extern "C" int jdgpu_batch_retries(const jdgpu_batch *b) { return b ? b->retries : 0; }
-#ifdef JD_STATS
-extern "C" int jdgpu_batch_debug_counters(jdgpu_batch *b, uint32_t out[16]) {
-    return hipMemcpy(out, b->d_changed, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+/* development aid: segments on the repair lists of the last pass, per round, summed over the images */
+extern "C" int jdgpu_batch_repair_counts(jdgpu_batch *b, uint32_t *out, size_t rounds) {
+    if (!b || !out) return JDGPU_ERR_ARG;
+    const size_t n = b->plan.n;
+    std::vector<uint32_t> h((size_t)JD_REPAIR_ROUNDS * (n ? n : 1));
+    HIPCHK(hipMemcpy(h.data(), b->d_list_cnt, h.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < rounds; ++r) {
+        out[r] = 0;
+        for (size_t i = 0; r < JD_REPAIR_ROUNDS && i < n; ++i) out[r] += h[r * n + i];
+    }
+    return JDGPU_OK;
 }
-#endif
 
 extern "C" void *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i) {
     if (!b || i >= b->plan.n) return nullptr;
