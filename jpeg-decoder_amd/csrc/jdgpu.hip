@@ -928,7 +928,10 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
                 uint4 *lp = reinterpret_cast<uint4 *>(s_buf + src * WBUF_BYTES + (((sub + src) & 7u) << 4));
                 uint4 v = *lp;
                 *lp = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4 *>(cbase + (size_t)blk * 64 + sub * 8) = v;
+                /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
+                uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64 + sub * 8);
+                __builtin_nontemporal_store(v.x, out); __builtin_nontemporal_store(v.y, out + 1);
+                __builtin_nontemporal_store(v.z, out + 2); __builtin_nontemporal_store(v.w, out + 3);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
