@@ -5,12 +5,12 @@
  * Pipeline of one jdgpu_batch_decode (all on one HIP stream, inputs resident in HBM):
  *
  *   unstuff   k_unstuff_*      stuffed scan bytes -> clean stream, one restart interval after
- *                              the other, each padded to whole 1024-bit segments
+ *                              the other, each padded to whole 4096-bit segments
  *                              (replaces src/bitstream.c:7-18 of the reference)
- *   sync      k_huff_sync      one lane per segment: decode speculatively from the segment
- *                              start, then re-decode from the predecessor's exit state until
- *                              the states of a 256-segment work-group stop changing
- *                              (self-synchronisation); k_huff_resync stitches work-groups
+ *   sync      k_huff_first     one lane per segment: guess the start state from the tail of
+ *                              the predecessor segment (self-synchronisation), decode
+ *             k_chain_check    list the segments whose start state is not their predecessor's
+ *             k_huff_repair    exit state and decode those again, a fixed number of rounds
  *   scan      k_seg_scan       segmented prefix sums: first data-unit index and DC predictors
  *                              at every segment start (src/jpeg.c:73, src/decoding.c:44)
  *   write     k_huff_write     final decode from the now-known start states; writes quantised
@@ -336,7 +336,7 @@ struct __attribute__((aligned(16))) BlkDesc {
     uint32_t dc_off, ac_off;   /* byte offsets of the unit's DC / AC lookup tables in the LDS copy */
     uint32_t slots;            /* dc slot | ac slot << 4 (canonical fallback only) */
     uint32_t pad;
-    int e0, e1, e2;            /* selects the unit's component: 1 / 0 (k_huff_sync, multiplied) or
+    int e0, e1, e2;            /* selects the unit's component: 1 / 0 (light decodes, multiplied) or
                                   -1 / 0 (k_huff_write, used as masks) */
     uint32_t pad2;
 };
