@@ -33,7 +33,7 @@ def _lib():
 
 def make_jpeg(w, h, seed=1234, quality=85, subsamp=1, restart_mcus=0):
     """Deterministic test-pattern JPEG.  subsamp: 1 = 4:2:0, 0 = 4:4:4."""
-    cap = w * h * 3 + 65536
+    cap = w * h * 6 + 65536   # white noise at quality 100 codes to more than the raw size
     buf = np.empty(cap, np.uint8)
     n = _lib().jsynth_make(w, h, seed, quality, subsamp, restart_mcus, buf.ctypes.data, cap)
     assert 0 < n <= cap
@@ -43,7 +43,7 @@ def make_jpeg(w, h, seed=1234, quality=85, subsamp=1, restart_mcus=0):
 def encode_rgb(rgb, quality=85, subsamp=1, restart_mcus=0):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     h, w = rgb.shape[:2]
-    cap = w * h * 3 + 65536
+    cap = w * h * 6 + 65536   # white noise at quality 100 codes to more than the raw size
     buf = np.empty(cap, np.uint8)
     n = _lib().jsynth_encode_rgb(rgb.ctypes.data, w, h, quality, subsamp, restart_mcus,
                                  buf.ctypes.data, cap)

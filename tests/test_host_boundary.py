@@ -145,6 +145,50 @@ def test_flattened_tables_equal_tree_walk(pkg):
     assert maxlen == 16  # the fixtures exercise the long-code path
 
 
+def _random_table(rng, n_sym, complete):
+    """random prefix code with n_sym symbols: split leaves of a random tree, lengths <= 16"""
+    lens = [1, 1]
+    while len(lens) < n_sym:
+        i = int(rng.integers(len(lens)))
+        if lens[i] >= 16:
+            if all(x >= 16 for x in lens):
+                break
+            continue
+        lens[i] += 1
+        lens.append(lens[i])
+    if not complete:
+        lens.remove(max(lens))          # leave part of the code space unused ("no such code")
+    counts = [lens.count(L) for L in range(1, 17)]
+    return counts
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_two_level_tables_random_codes(pkg, seed):
+    """random prefix codes (deep, shallow, complete and incomplete): the two-level lookup ==
+    the bitwise walk on every 16-bit window, including the consumed length of failing walks
+    being reported as failures"""
+    rng = np.random.default_rng(seed)
+    n_sym = [2, 12, 40, 162, 200, 256][seed % 6]
+    counts = _random_table(rng, n_sym, complete=seed % 2 == 0)
+    total = sum(counts)
+    spec = pkg.HuffSpec()
+    syms = list(rng.permutation(256)[:total])
+    for i in range(16):
+        spec.counts[i] = counts[i]
+    for i, sy in enumerate(syms):
+        spec.symbols[i] = int(sy)
+    L = pkg.lib()
+    ln, run, size = C.c_uint(), C.c_uint(), C.c_uint()
+    for v in range(65536):
+        rc = L.jdgpu_host_lut_lookup(C.byref(spec), 0, v, C.byref(ln), C.byref(run), C.byref(size))
+        want = _canonical_decode(counts, syms, v)
+        if want is None:
+            assert rc == -1
+        else:
+            assert rc == 0 and ln.value == want[0]
+            assert (run.value, size.value) == (want[1] >> 4, want[1] & 15)
+
+
 def _ref_reader_bytes(scan):
     """the reference's byte reader (src/bitstream.c:7-18): data bytes in the order they are used"""
     out, i = bytearray(), 0
