@@ -167,7 +167,9 @@ typedef struct {
     size_t n;
     jd_image *img;           /* [n] */
     jd_lut *luts;            /* [n * JD_LUT_SLOTS] */
-    uint8_t *raw;            /* concatenated stuffed scans, each padded to 16 B */
+    uint8_t *raw;            /* concatenated stuffed scans, each padded to 16 B: staging memory set by the caller
+                                before jd_plan_gather(), not owned unless raw_owned */
+    int raw_owned;
     size_t raw_bytes;
     size_t clean_bytes;      /* capacity of the clean stream buffer */
     uint32_t n_segs_cap;     /* total segment capacity */
@@ -184,6 +186,7 @@ typedef struct {
 } jd_plan;
 
 int  jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *plan, char *err, size_t errlen);
+void jd_plan_gather(jd_plan *plan, const jdgpu_image_desc *descs, size_t n); /* copies the scans into plan->raw (threads) */
 void jd_plan_unstuff_host(jd_plan *plan);
 void jd_plan_free(jd_plan *plan);
 int  jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut);

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Development aid: what the caller side costs (run on the GPU box): header parsing, batch
+creation (plan + gather + upload; JDGPU_TRACE=1 prints the parts) and the PCIe-inclusive rate."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+import bench
+files = bench.make_files(pkg, "c3", 64, 0)
+dec = pkg.Decoder(0)
+t = time.perf_counter(); descs = [pkg.parse(f) for f in files]; tp = (time.perf_counter() - t) / len(files)
+use = [descs[i % 64] for i in range(4096)]
+for attempt in ("first", "second"):
+    t = time.perf_counter(); b = pkg.Batch(use); tc = time.perf_counter() - t
+    b.decode()
+    t = time.perf_counter(); b.decode(); td = time.perf_counter() - t
+    print(f"{attempt} batch: parse {tp*1e6:.1f} us/image; batch_create(4096) {tc*1e3:.1f} ms; decode {td*1e3:.1f} ms; "
+          f"scan {b.total_scan_bytes/1e9:.2f} GB; PCIe-inclusive {b.total_pixels/(tc+td)/1e6:.0f} Mpixel/s, "
+          f"resident {b.total_pixels/td/1e6:.0f} Mpixel/s")
+    b.close()
