@@ -171,6 +171,21 @@ def main():
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": alg[stage], "avg_ms": round(stage_ms[stage], 4)}
 
+        def with_traffic(r):
+            """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json):
+            measured on the same workload shape at 256 images per launch, scaled per pixel to this
+            launch; null for workloads the passes did not cover"""
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                k = t["kernels"].get(r["kernel"])
+                if args.workload == "c3" and k:
+                    per_px = (2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024 / (t["images"] * t["pixels_per_image"])
+                    r["traffic"] = int(per_px * pixels)
+                    r["traffic_source"] = "PMC FETCH_SIZE x2 + WRITE_SIZE (KiB), 256-image launch, scaled per pixel"
+            except (OSError, ValueError, KeyError):
+                pass
+            return r
+
         dominant = max((s for s in alg if s != "scan"), key=lambda s: stage_ms.get(s, 0.0))
         out = {
             "metric": "decoded Mpixels/s", "value": round(value, 1), "unit": "Mpixel/s",
@@ -180,8 +195,8 @@ def main():
             "config": {"workload": desc, "batch_per_gpu": batch_n, "distinct_images": len(files),
                        "pixels_per_step_per_gpu": pixels, "scan_bytes_per_step_per_gpu": batch.total_scan_bytes,
                        "parallelism": f"image-sharded x{world}, no collective"},
-            "roofline": roof(dominant),
-            "pixel_stage": roof("pixel"),
+            "roofline": with_traffic(roof(dominant)),
+            "pixel_stage": with_traffic(roof("pixel")),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stitch_retries": retries,
         }
