@@ -1041,13 +1041,15 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
             ct[3] = ct[2];
         }
     }
+    /* wave-uniform: almost no wave ever meets the exceptional chroma pair */
+    const bool any_exc = !OUT_YCBCR && __any((int)(ct[0].exc | ct[1].exc | ct[2].exc | ct[3].exc));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int Y = (int)((y4 >> (8 * i)) & 255u);
         if (OUT_YCBCR) { o[3 * i] = (uint32_t)Y; o[3 * i + 1] = cbv[i]; o[3 * i + 2] = crv[i]; }
         else {
             o[3 * i] = clamp255(Y + ct[i].dr);
-            o[3 * i + 1] = clamp255(Y + ct[i].dg - green_fix(ct[i], Y));
+            o[3 * i + 1] = clamp255(Y + ct[i].dg - (any_exc ? green_fix(ct[i], Y) : 0));
             o[3 * i + 2] = clamp255(Y + ct[i].db);
         }
     }
@@ -1101,6 +1103,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][3 * PLANE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
     __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 */
+    __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
 
     const jd_pix_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
@@ -1113,6 +1116,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
                       ((uint32_t)im.comp_H[c] << 8);
     }
+    if (tid < 8 * JD_MAX_BPM) s_jmap[tid] = (uint16_t)((tid / bpm) | ((tid % bpm) << 8));
     const uint32_t mcu_first = wg.mcu_col0 + wave * sub_mcus;          /* first MCU column of this wave */
     const uint32_t my_mcus = mcu_first < im.mcus_x ? min(sub_mcus, im.mcus_x - mcu_first) : 0u;
     const uint32_t nblk = my_mcus * bpm;
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
             uint32_t m = 0, b = 0, meta = 0;
             double col[8], t[8];
             if (act) {
-                m = j / bpm; b = j - m * bpm; meta = s_meta[b];
+                const uint32_t jm = s_jmap[j]; m = jm & 255u; b = jm >> 8; meta = s_meta[b];
                 uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
                 const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
