@@ -164,7 +164,8 @@ static void scale_q(const uint8_t base[64], int quality, uint8_t out[64]) {
 }
 
 /*
- * Encode interleaved RGB (w*h*3).  subsamp: 0 = 4:4:4, 1 = 4:2:0.  restart_mcus: 0 = no DRI.
+ * Encode interleaved RGB (w*h*3).  subsamp: 0 = 4:4:4, 1 = 4:2:0, 2 = 4:2:2 (luma 2x1),
+ * 3 = 4:4:0 (luma 1x2).  restart_mcus: 0 = no DRI.
  * Returns the number of bytes the stream needs; if it exceeds cap the buffer content is
  * undefined (call again with a bigger buffer).
  */
@@ -174,9 +175,10 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
     obuf o = {out, 0, cap, 0, 0, 0};
     uint8_t ql[64], qc[64];
     scale_q(K_LUMA_Q, quality, ql); scale_q(K_CHROMA_Q, quality, qc);
-    int ss = subsamp ? 2 : 1, mcu = 8 * ss;
-    int mx = (w + mcu - 1) / mcu, my = (h + mcu - 1) / mcu;
-    int pw = mx * mcu, ph = my * mcu;
+    int ssh = (subsamp == 1 || subsamp == 2) ? 2 : 1, ssv = (subsamp == 1 || subsamp == 3) ? 2 : 1;
+    int mcuw = 8 * ssh, mcuh = 8 * ssv;
+    int mx = (w + mcuw - 1) / mcuw, my = (h + mcuh - 1) / mcuh;
+    int pw = mx * mcuw, ph = my * mcuh;
 
     /* planes, edge-replicated to the padded size */
     float *Y = malloc(sizeof(float) * (size_t)pw * ph), *Cb = malloc(sizeof(float) * (size_t)pw * ph),
@@ -201,7 +203,7 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
     put8(&o, 1); for (int k = 0; k < 64; ++k) put8(&o, qc[ZZ[k]]);
     /* SOF0 */
     put16(&o, 0xFFC0); put16(&o, 8 + 9); put8(&o, 8); put16(&o, (unsigned)h); put16(&o, (unsigned)w); put8(&o, 3);
-    put8(&o, 1); put8(&o, (ss << 4) | ss); put8(&o, 0);
+    put8(&o, 1); put8(&o, (ssh << 4) | ssv); put8(&o, 0);
     put8(&o, 2); put8(&o, 0x11); put8(&o, 1);
     put8(&o, 3); put8(&o, 0x11); put8(&o, 1);
     put_dht(&o, 0x00, DC_L_BITS, DC_VALS); put_dht(&o, 0x10, AC_L_BITS, AC_L_VALS);
@@ -226,9 +228,9 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
                 put16(&o, 0xFFD0 + (rst & 7)); ++rst;
                 pred[0] = pred[1] = pred[2] = 0;
             }
-            for (int v = 0; v < ss; ++v)
-                for (int hh = 0; hh < ss; ++hh) {
-                    int bx = i * mcu + 8 * hh, by = j * mcu + 8 * v;
+            for (int v = 0; v < ssv; ++v)
+                for (int hh = 0; hh < ssh; ++hh) {
+                    int bx = i * mcuw + 8 * hh, by = j * mcuh + 8 * v;
                     for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) s[y * 8 + x] = Y[(size_t)(by + y) * pw + bx + x] - 128.0;
                     fdct_quant(s, ql, qz);
                     encode_block(&o, qz, &pred[0], &dcl, &acl);
@@ -237,9 +239,9 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
                 const float *P = c == 1 ? Cb : Cr;
                 for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
                     double a = 0;
-                    for (int dy = 0; dy < ss; ++dy) for (int dx = 0; dx < ss; ++dx)
-                        a += P[(size_t)(j * mcu + y * ss + dy) * pw + i * mcu + x * ss + dx];
-                    s[y * 8 + x] = a / (ss * ss) - 128.0;
+                    for (int dy = 0; dy < ssv; ++dy) for (int dx = 0; dx < ssh; ++dx)
+                        a += P[(size_t)(j * mcuh + y * ssv + dy) * pw + i * mcuw + x * ssh + dx];
+                    s[y * 8 + x] = a / (ssh * ssv) - 128.0;
                 }
                 fdct_quant(s, qc, qz);
                 encode_block(&o, qz, &pred[c], &dcc, &acc_);

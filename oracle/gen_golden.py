@@ -34,7 +34,7 @@ EXAMPLES = ["birb.jpg", "pineapple.jpg", "no_subsampling/ferris_wheel.jpg",
             "no_subsampling/lake.jpg", "no_subsampling/pineapple.jpg",
             "no_subsampling/skyline.jpg"]
 
-# (name, w, h, seed, quality, subsamp(0=444,1=420), restart_mcus)
+# (name, w, h, seed, quality, subsamp(0=444,1=420,2=422,3=440), restart_mcus)
 SYNTH = [
     ("syn_64x48_420_q85", 64, 48, 1, 85, 1, 0),
     ("syn_64x48_444_q85", 64, 48, 2, 85, 0, 0),
@@ -44,6 +44,9 @@ SYNTH = [
     ("syn_16x16_420_q85", 16, 16, 6, 85, 1, 0),
     ("syn_8x8_444_q85", 8, 8, 7, 85, 0, 0),
     ("syn_640x360_420_q85", 640, 360, 8, 85, 1, 0),
+    ("syn_96x40_422_q80", 96, 40, 9, 80, 2, 0),
+    ("syn_72x96_440_q75", 72, 96, 10, 75, 3, 0),
+    ("syn_320x240_422_q90", 320, 240, 11, 90, 2, 0),
 ]
 # DRI twins of non-DRI streams: (name, base name, restart_mcus)
 SYNTH_DRI = [
