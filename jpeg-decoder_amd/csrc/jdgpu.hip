@@ -1098,7 +1098,8 @@ template <bool OUT_YCBCR>
 __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__restrict__ imgs,
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
-                                               uint8_t *__restrict__ pix) {
+                                               uint8_t *__restrict__ pix,
+                                               uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][3 * PLANE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
@@ -1123,127 +1124,158 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 
     /* ---- phase 1 ---- */
     const uint32_t l = lane & 7u, slot = lane >> 3;
-    /* the wave's data units are consecutive in the coefficient buffer */
-    const int16_t *cbase = coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64 + l * 8;
     /* transpose buffer: element (y, u) of slot s at s*64 + y*8 + (((u + y) & 7) ^ (s & 3)):
      * the 32 lanes of a half-wave that read (their y, step u) hit 32 different bank pairs */
     double *tr = s_tr + (wave * 8u + slot) * TR_BLK;
     uint8_t *tile = s_tile[wave];
     const uint32_t sx = slot & 3u;
-    /* all coefficient loads of up to three 8-unit steps are issued before the first transform:
-     * ~3 KB in flight per wave is what it takes to cover HBM latency at 20 waves per CU */
     __syncthreads();
     if (nblk == 0) return;
-    for (uint32_t r0 = 0; r0 < nblk; r0 += 24) {
-        uint4 rawv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            uint32_t j = r0 + 8u * i + slot;
-            rawv[i] = make_uint4(0, 0, 0, 0);
-            if (j < nblk) rawv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const uint32_t j = r0 + 8u * i + slot;
-            if (r0 + 8u * i >= nblk) break; /* wave-uniform */
-            const bool act = j < nblk;
-            const uint4 raw = rawv[i];
-            uint32_t m = 0, b = 0, meta = 0;
-            double col[8], t[8];
-            if (act) {
-                const uint32_t jm = s_jmap[j]; m = jm & 255u; b = jm >> 8; meta = s_meta[b];
-                uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
-                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
-                    col[2 * q] = (double)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                    col[2 * q + 1] = (double)__mul24(hi, (int)(qw[q] >> 16));
-                }
-                idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
-#pragma unroll
-                for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
-            }
-            WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
-            if (act) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
-                idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
-                uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    w0 |= to_sample(t[x]) << (8 * x);
-                    w1 |= to_sample(t[x + 4]) << (8 * x);
-                }
-                uint32_t row = ((meta >> 6) & 3u) * 8u + l;
-                uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
-                *reinterpret_cast<uint2 *>(&tile[(meta & 3u) * PLANE_BYTES + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
-            }
-            WAVE_SYNC();
-        }
-    }
-
-    /* ---- phase 2 ---- */
+    const uint32_t row_end = min((uint32_t)wg.mcu_row + pix_rows, im.mcus_y);
+    /* the wave's data units of one MCU row are consecutive in the coefficient buffer; lane: its
+     * 16-byte column of unit `slot` */
+    const size_t row_stride = (size_t)im.mcus_x * bpm * 64;
+    const int16_t *cbase = coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64 + l * 8;
     const uint32_t W = im.width, H = im.height;
-    const uint32_t x0 = mcu_first * 8u * maxH, y0 = wg.mcu_row * 8u * maxV;
-    const uint32_t rows = min(8u * maxV, H - y0);
+    const uint32_t x0 = mcu_first * 8u * maxH;
     const uint32_t g = lane & 15u, rq = lane >> 4, x = x0 + 4u * g;
     uint8_t *out = pix + im.pix_off;
     const bool aligned = ((W & 3u) == 0);
-    if (!(x < W && 4u * g < my_mcus * 8u * maxH)) return;
-    const uint32_t npx = min(4u, W - x);
+    const bool draws = x < W && 4u * g < my_mcus * 8u * maxH;   /* lane has pixels in phase 2 */
+    const uint32_t npx = draws ? min(4u, W - x) : 0u;
     const uint32_t mode = im.pix_mode;
     const uint8_t *tY = tile, *tB = tile + PLANE_BYTES, *tR = tile + 2 * PLANE_BYTES;
-    if (mode == JD_PIX_420) {
-        /* lane: 4 pixels x 2 rows sharing one chroma row */
-        for (uint32_t rp = rq; 2u * rp < rows; rp += 4) {
-            uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[rp * PIX_ROW + 2u * g]);
-            uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[rp * PIX_ROW + 2u * g]);
-            const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
-            const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
+
+    /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
+     * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
+     * out the HBM latency, computed and left spent a third of its life in that wait. */
+    uint4 nextv[3];
 #pragma unroll
-            for (uint32_t dy = 0; dy < 2; ++dy) {
-                uint32_t r = 2u * rp + dy;
-                if (r < rows) {
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t j = 8u * i + slot;
+        nextv[i] = make_uint4(0, 0, 0, 0);
+        if (j < nblk) nextv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+    }
+    for (uint32_t mrow = wg.mcu_row; mrow < row_end; ++mrow, cbase += row_stride) {
+        uint4 curv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) curv[i] = nextv[i];
+        if (mrow + 1 < row_end) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t j = 8u * i + slot;
+                if (j < nblk) nextv[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
+            }
+        }
+        for (uint32_t r0 = 0; r0 < nblk; r0 += 24) {
+            uint4 rawv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rawv[i] = curv[i];
+                if (r0) { /* layouts with more than 24 units per wave and row: loaded in place */
+                    const uint32_t j = r0 + 8u * i + slot;
+                    rawv[i] = make_uint4(0, 0, 0, 0);
+                    if (j < nblk) rawv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t j = r0 + 8u * i + slot;
+                if (r0 + 8u * i >= nblk) break; /* wave-uniform */
+                const bool act = j < nblk;
+                const uint4 raw = rawv[i];
+                uint32_t m = 0, b = 0, meta = 0;
+                double col[8], t[8];
+                if (act) {
+                    const uint32_t jm = s_jmap[j]; m = jm & 255u; b = jm >> 8; meta = s_meta[b];
+                    uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
+                    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
+                        col[2 * q] = (double)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                        col[2 * q + 1] = (double)__mul24(hi, (int)(qw[q] >> 16));
+                    }
+                    idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
+                }
+                WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
+                if (act) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
+                    idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
+                    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx) {
+                        w0 |= to_sample(t[xx]) << (8 * xx);
+                        w1 |= to_sample(t[xx + 4]) << (8 * xx);
+                    }
+                    uint32_t row = ((meta >> 6) & 3u) * 8u + l;
+                    uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
+                    *reinterpret_cast<uint2 *>(&tile[(meta & 3u) * PLANE_BYTES + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+                }
+                WAVE_SYNC();
+            }
+        }
+
+        /* ---- phase 2 ---- */
+        const uint32_t y0 = mrow * 8u * maxV;
+        const uint32_t rows = min(8u * maxV, H - y0);
+        if (draws) {
+            if (mode == JD_PIX_420) {
+                /* lane: 4 pixels x 2 rows sharing one chroma row */
+                for (uint32_t rp = rq; 2u * rp < rows; rp += 4) {
+                    uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[rp * PIX_ROW + 2u * g]);
+                    uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[rp * PIX_ROW + 2u * g]);
+                    const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
+                    const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
+#pragma unroll
+                    for (uint32_t dy = 0; dy < 2; ++dy) {
+                        uint32_t r = 2u * rp + dy;
+                        if (r < rows) {
+                            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
+                            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
+                            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                        }
+                    }
+                }
+            } else if (mode == JD_PIX_444) {
+                for (uint32_t r = rq; r < rows; r += 4) {
                     uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
-                    Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
+                    uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[r * PIX_ROW + 4u * g]);
+                    uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[r * PIX_ROW + 4u * g]);
+                    const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
+                    const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
+                    Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
+                    store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                }
+            } else {
+                /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
+                 * replication shift per component: maxH/H, maxV/V in {1,2} (src/jpeg.c:82) */
+                uint32_t hs[3], vs[3], ch[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
+                }
+                for (uint32_t r = rq; r < rows; r += 4) {
+                    uint32_t sm[3][4]; /* sm[channel][pixel]; channel = component id - 1 (src/decoding.c:107) */
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint8_t *tp = &tile[c * PLANE_BYTES + (r >> vs[c]) * PIX_ROW];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            uint32_t v = tp[(4u * g + i) >> hs[c]];
+                            if (ch[c] == 0) sm[0][i] = v; else if (ch[c] == 1) sm[1][i] = v; else sm[2][i] = v;
+                        }
+                    }
+                    uint32_t y4 = sm[0][0] | (sm[0][1] << 8) | (sm[0][2] << 16) | (sm[0][3] << 24);
+                    Px4 v = colour4<OUT_YCBCR>(y4, sm[1], sm[2], 4);
                     store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
                 }
             }
         }
-    } else if (mode == JD_PIX_444) {
-        for (uint32_t r = rq; r < rows; r += 4) {
-            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
-            uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[r * PIX_ROW + 4u * g]);
-            uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[r * PIX_ROW + 4u * g]);
-            const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
-            const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
-            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
-            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
-        }
-    } else {
-        /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
-         * replication shift per component: maxH/H, maxV/V in {1,2} (src/jpeg.c:82) */
-        uint32_t hs[3], vs[3], ch[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
-        }
-        for (uint32_t r = rq; r < rows; r += 4) {
-            uint32_t s[3][4]; /* s[channel][pixel]; channel = component id - 1 (src/decoding.c:107) */
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint8_t *tp = &tile[c * PLANE_BYTES + (r >> vs[c]) * PIX_ROW];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t v = tp[(4u * g + i) >> hs[c]];
-                    if (ch[c] == 0) s[0][i] = v; else if (ch[c] == 1) s[1][i] = v; else s[2][i] = v;
-                }
-            }
-            uint32_t y4 = s[0][0] | (s[0][1] << 8) | (s[0][2] << 16) | (s[0][3] << 24);
-            Px4 v = colour4<OUT_YCBCR>(y4, s[1], s[2], 4);
-            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
-        }
+        WAVE_SYNC(); /* the tile is rewritten by the next row */
     }
 }
 
@@ -1504,9 +1536,9 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
     if (P.n_pwg) {
         if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
         else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[5], st));
     HIPCHK(hipGetLastError());
@@ -1546,9 +1578,9 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
         else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix);
+            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
         HIPCHK(hipStreamSynchronize(s));
     }
     for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);

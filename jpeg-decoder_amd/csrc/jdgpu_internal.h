@@ -149,7 +149,7 @@ typedef struct {
 
 /* work descriptors: one per work-group */
 typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* JD_WG_SEGS segments from seg0 */
-typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of an MCU row */
+typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of jd_plan::pix_rows MCU rows from mcu_row */
 typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */
 #define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
 
@@ -157,6 +157,8 @@ typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK
 #define JD_PIX_WAVES 4u    /* waves per pixel-kernel work-group; each wave owns 64 pixels of the strip */
 #endif
 #define JD_STRIP_PX (64u * JD_PIX_WAVES)  /* pixel-kernel strip width */
+#define JD_PIX_ROWS_MAX 16u  /* MCU rows a pixel-kernel work-group walks down at most (loads run one row ahead);
+                                the plan takes fewer when the batch is too small to fill the chip otherwise */
 #define JD_PIX_GENERIC 0u
 #define JD_PIX_420 1u     /* ids 1,2,3 in scan order, Y 2x2, Cb/Cr 1x1 */
 #define JD_PIX_444 2u     /* ids 1,2,3 in scan order, all 1x1 */
@@ -176,7 +178,7 @@ typedef struct {
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
     jd_huff_wg *wwg; uint32_t n_wwg;   /* same segments in groups of JD_WWG_SEGS */
-    jd_pix_wg *pwg;  uint32_t n_pwg;
+    jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
     jd_raw_wg *rwg;  uint32_t n_rwg;
     uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;

@@ -243,10 +243,15 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         nh += (im->seg_cap + JD_WG_SEGS - 1) / JD_WG_SEGS;
         nw += (im->seg_cap + JD_WWG_SEGS - 1) / JD_WWG_SEGS;
         uint32_t strip = JD_STRIP_PX / (8u * maxH);
-        np += im->mcus_y * ((im->mcus_x + strip - 1) / strip);
+        np += im->mcus_y * ((im->mcus_x + strip - 1) / strip); /* single-row strips: regrouped below */
     }
     P->raw_bytes = raw + 64; P->clean_bytes = clean + JD_SEG_BYTES * 2;
     P->n_segs_cap = segs; P->n_intervals = ivls; P->total_blocks = blk; P->pix_bytes = pix;
+    /* rows per pixel work-group: as many as leave ~8 work-groups per CU slot round */
+    {
+        uint32_t rows = np / 8192u;
+        P->pix_rows = rows < 1 ? 1 : rows > JD_PIX_ROWS_MAX ? JD_PIX_ROWS_MAX : rows;
+    }
     P->n_hwg = nh; P->n_pwg = np; P->n_rwg = nr; P->n_u = nu;
     P->rwg = calloc(nr ? nr : 1, sizeof *P->rwg);
     P->n_wwg = nw;
@@ -263,11 +268,12 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WWG_SEGS) { P->wwg[nw].img = (uint32_t)i; P->wwg[nw].seg0 = s; ++nw; }
         uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
-        for (uint32_t r = 0; r < im->mcus_y; ++r)
+        for (uint32_t r = 0; r < im->mcus_y; r += P->pix_rows)
             for (uint32_t c = 0; c < im->mcus_x; c += strip) {
                 P->pwg[np].img = (uint32_t)i; P->pwg[np].mcu_row = (uint16_t)r; P->pwg[np].mcu_col0 = (uint16_t)c; ++np;
             }
     }
+    P->n_pwg = np; /* after grouping rows */
     return JDGPU_OK;
 }
 
