@@ -47,7 +47,7 @@ static thread_local char g_err[512] = "";
     } while (0)
 
 #define SEG_MASK 0xFFFFu /* valid-bit count in a per-segment word */
-#define JD_REPAIR_ROUNDS 6u /* chain check + repair launches per pass */
+#define JD_REPAIR_ROUNDS 10u /* chain check + repair launches per pass */
 
 /* The clean stream is stored transposed in groups of 64 segments, 16 bytes at a time: bytes
  * [16q, 16q+16) of segment s live at [(s / 64) * (JD_SEG_BYTES/16) + q][s % 64], so the 64 lanes
