@@ -108,10 +108,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # JD_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the N > 1 control flow
+    # on a one-GPU box (the real N > 1 run is one rank per GPU over RCCL)
+    rehearsal = bool(os.environ.get("JD_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
     dec = pkg.Decoder(local_rank)
@@ -145,7 +153,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     retries = batch.retries
