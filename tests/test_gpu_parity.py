@@ -183,6 +183,23 @@ def test_full_size_1080p(pkg, dec, oracle):
     assert np.array_equal(out.rgb(2), out.rgb(0))
 
 
+def test_large_image_many_segments(pkg, dec, oracle):
+    """8192 x 4096 (33.5 Mpixel, ~1.5 M data units, > 11 000 segments in one image): work-group
+    lists, 32-bit stream offsets and the per-image scans at a size far from the fixtures;
+    coefficients against the oracle, pixels against the restart-marker twin"""
+    plain = pkg.synth.make_jpeg(8192, 4096, seed=31, quality=80, subsamp=1)
+    dri = pkg.synth.make_jpeg(8192, 4096, seed=31, quality=80, subsamp=1, restart_mcus=512)
+    out = dec.decode([plain, dri])
+    assert out.status(0) == 0 and out.status(1) == 0
+    rc, info, q = oracle.qcoef(plain)
+    assert rc == 0 and np.array_equal(out.qcoef(0).astype(np.int32), q)
+    assert np.array_equal(out.qcoef(1), out.qcoef(0))
+    a, b = out.rgb(0), out.rgb(1)
+    assert np.array_equal(a, b)
+    rc, ref = oracle.rgb(plain, honour_dri=True)
+    assert rc == 0 and np.array_equal(a, ref)
+
+
 def test_full_size_4k_restart_rows(pkg, dec, oracle):
     """BASELINE config 4 shape: 3840x2160 4:2:0, DRI = one MCU row; size-independent property:
     identical output to the same pixels encoded without restart markers"""
