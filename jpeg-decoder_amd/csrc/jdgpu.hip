@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t off, const Px4 &v
  *            contiguous bytes of an output row.
  * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces).
  */
-template <bool OUT_YCBCR>
+template <bool OUT_YCBCR, uint32_t MODE>
 __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__restrict__ imgs,
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
@@ -1109,7 +1109,10 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const jd_pix_wg wg = wgs[blockIdx.x];
     const jd_image &im = imgs[wg.img];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t maxH = im.maxH, maxV = im.maxV, bpm = im.bpm;
+    /* one instantiation per pixel layout: the common ones get their geometry as constants */
+    const uint32_t maxH = MODE == JD_PIX_420 ? 2u : MODE == JD_PIX_444 ? 1u : im.maxH;
+    const uint32_t maxV = MODE == JD_PIX_420 ? 2u : MODE == JD_PIX_444 ? 1u : im.maxV;
+    const uint32_t bpm = MODE == JD_PIX_420 ? 6u : MODE == JD_PIX_444 ? 3u : im.bpm;
     const uint32_t sub_mcus = SUB_PX / (8u * maxH);
     for (uint32_t i = tid; i < 256; i += 64 * JD_PIX_WAVES) s_q[i >> 6][i & 63u] = im.quant[i >> 6][i & 63u];
     if (tid < JD_MAX_BPM) {
@@ -1143,7 +1146,6 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const bool aligned = ((W & 3u) == 0);
     const bool draws = x < W && 4u * g < my_mcus * 8u * maxH;   /* lane has pixels in phase 2 */
     const uint32_t npx = draws ? min(4u, W - x) : 0u;
-    const uint32_t mode = im.pix_mode;
     const uint8_t *tY = tile, *tB = tile + PLANE_BYTES, *tR = tile + 2 * PLANE_BYTES;
 
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         const uint32_t y0 = mrow * 8u * maxV;
         const uint32_t rows = min(8u * maxV, H - y0);
         if (draws) {
-            if (mode == JD_PIX_420) {
+            if (MODE == JD_PIX_420) {
                 /* lane: 4 pixels x 2 rows sharing one chroma row */
                 for (uint32_t rp = rq; 2u * rp < rows; rp += 4) {
                     uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[rp * PIX_ROW + 2u * g]);
@@ -1240,7 +1242,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         }
                     }
                 }
-            } else if (mode == JD_PIX_444) {
+            } else if (MODE == JD_PIX_444) {
                 for (uint32_t r = rq; r < rows; r += 4) {
                     uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
                     uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[r * PIX_ROW + 4u * g]);
@@ -1485,6 +1487,25 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     return JDGPU_OK;
 }
 
+template <bool OUT_YCBCR>
+static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
+    jd_plan &P = b->plan;
+    const dim3 block(64 * JD_PIX_WAVES);
+    const uint32_t *f = P.pwg_mode_first;
+    if (f[JD_PIX_GENERIC + 1] > f[JD_PIX_GENERIC])
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_GENERIC>), dim3(f[JD_PIX_GENERIC + 1] - f[JD_PIX_GENERIC]), block, 0, st,
+                           b->d_img, b->d_pwg + f[JD_PIX_GENERIC], b->d_coef, b->d_pix, P.pix_rows);
+    if (f[JD_PIX_420 + 1] > f[JD_PIX_420])
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_420>), dim3(f[JD_PIX_420 + 1] - f[JD_PIX_420]), block, 0, st,
+                           b->d_img, b->d_pwg + f[JD_PIX_420], b->d_coef, b->d_pix, P.pix_rows);
+    if (f[JD_PIX_444 + 1] > f[JD_PIX_444])
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_444>), dim3(f[JD_PIX_444 + 1] - f[JD_PIX_444]), block, 0, st,
+                           b->d_img, b->d_pwg + f[JD_PIX_444], b->d_coef, b->d_pix, P.pix_rows);
+}
+static void launch_pixel(jdgpu_batch *b, hipStream_t st) {
+    if (b->flags & JDGPU_OUT_YCBCR) launch_pixel_modes<true>(b, st); else launch_pixel_modes<false>(b, st);
+}
+
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     jd_plan &P = b->plan;
     hipStream_t st = b->stream;
@@ -1535,10 +1556,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
     if (P.n_pwg) {
-        if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
-        else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, st, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
+        launch_pixel(b, st);
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[5], st));
     HIPCHK(hipGetLastError());
@@ -1577,10 +1595,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
-        if (b->flags & JDGPU_OUT_YCBCR)
-            hipLaunchKernelGGL(k_pixel<true>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
-        else
-            hipLaunchKernelGGL(k_pixel<false>, dim3(P.n_pwg), dim3(64 * JD_PIX_WAVES), 0, s, b->d_img, b->d_pwg, b->d_coef, b->d_pix, P.pix_rows);
+        launch_pixel(b, s);
         HIPCHK(hipStreamSynchronize(s));
     }
     for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);

@@ -179,6 +179,7 @@ typedef struct {
     jd_huff_wg *hwg; uint32_t n_hwg;
     jd_huff_wg *wwg; uint32_t n_wwg;   /* same segments in groups of JD_WWG_SEGS */
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
+    uint32_t pwg_mode_first[4]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
     jd_raw_wg *rwg;  uint32_t n_rwg;
     uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;

@@ -267,12 +267,21 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         for (uint32_t ch = 0; ch < im->n_chunks; ++ch) { P->rwg[nr].img = (uint32_t)i; P->rwg[nr].chunk = ch; ++nr; }
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
         for (uint32_t s = 0; s < im->seg_cap; s += JD_WWG_SEGS) { P->wwg[nw].img = (uint32_t)i; P->wwg[nw].seg0 = s; ++nw; }
-        uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
-        for (uint32_t r = 0; r < im->mcus_y; r += P->pix_rows)
-            for (uint32_t c = 0; c < im->mcus_x; c += strip) {
-                P->pwg[np].img = (uint32_t)i; P->pwg[np].mcu_row = (uint16_t)r; P->pwg[np].mcu_col0 = (uint16_t)c; ++np;
-            }
     }
+    /* pixel work-groups, grouped by layout (one kernel instantiation each) */
+    for (uint32_t mode = 0; mode < 3; ++mode) {
+        P->pwg_mode_first[mode] = np;
+        for (size_t i = 0; i < n; ++i) {
+            jd_image *im = &P->img[i];
+            if (!im->ncomp || im->pix_mode != mode) continue;
+            uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
+            for (uint32_t r = 0; r < im->mcus_y; r += P->pix_rows)
+                for (uint32_t c = 0; c < im->mcus_x; c += strip) {
+                    P->pwg[np].img = (uint32_t)i; P->pwg[np].mcu_row = (uint16_t)r; P->pwg[np].mcu_col0 = (uint16_t)c; ++np;
+                }
+        }
+    }
+    P->pwg_mode_first[3] = np;
     P->n_pwg = np; /* after grouping rows */
     return JDGPU_OK;
 }
