@@ -1101,9 +1101,13 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                uint8_t *__restrict__ pix,
                                                uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][3 * PLANE_BYTES];
+    /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
+    constexpr uint32_t PLANE1 = MODE == JD_PIX_420 ? 16u * PIX_ROW : MODE == JD_PIX_444 ? 8u * PIX_ROW : PLANE_BYTES;
+    constexpr uint32_t PLANE2 = PLANE1 + (MODE == JD_PIX_GENERIC ? PLANE_BYTES : 8u * PIX_ROW);
+    constexpr uint32_t TILE_BYTES = PLANE2 + (MODE == JD_PIX_GENERIC ? PLANE_BYTES : 8u * PIX_ROW);
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
-    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 */
+    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
     __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
 
     const jd_pix_wg wg = wgs[blockIdx.x];
@@ -1117,8 +1121,9 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     for (uint32_t i = tid; i < 256; i += 64 * JD_PIX_WAVES) s_q[i >> 6][i & 63u] = im.quant[i >> 6][i & 63u];
     if (tid < JD_MAX_BPM) {
         uint32_t c = im.blk_comp[tid];
+        const uint32_t plane = c == 0 ? 0u : c == 1 ? PLANE1 : PLANE2;   /* multiples of 64 bytes */
         s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
-                      ((uint32_t)im.comp_H[c] << 8);
+                      ((uint32_t)im.comp_H[c] << 8) | ((plane >> 6) << 12);
     }
     if (tid < 8 * JD_MAX_BPM) s_jmap[tid] = (uint16_t)((tid / bpm) | ((tid % bpm) << 8));
     const uint32_t mcu_first = wg.mcu_col0 + wave * sub_mcus;          /* first MCU column of this wave */
@@ -1146,7 +1151,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const bool aligned = ((W & 3u) == 0);
     const bool draws = x < W && 4u * g < my_mcus * 8u * maxH;   /* lane has pixels in phase 2 */
     const uint32_t npx = draws ? min(4u, W - x) : 0u;
-    const uint8_t *tY = tile, *tB = tile + PLANE_BYTES, *tR = tile + 2 * PLANE_BYTES;
+    const uint8_t *tY = tile, *tB = tile + PLANE1, *tR = tile + PLANE2;
 
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
@@ -1214,8 +1219,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         w1 |= to_sample(t[xx + 4]) << (8 * xx);
                     }
                     uint32_t row = ((meta >> 6) & 3u) * 8u + l;
-                    uint32_t colpx = (m * (meta >> 8) + ((meta >> 4) & 3u)) * 8u;
-                    *reinterpret_cast<uint2 *>(&tile[(meta & 3u) * PLANE_BYTES + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+                    uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
+                    *reinterpret_cast<uint2 *>(&tile[(meta >> 12) * 64u + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
                 }
                 WAVE_SYNC();
             }
