@@ -1156,41 +1156,27 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
      * out the HBM latency, computed and left spent a third of its life in that wait. */
-    uint4 nextv[3];
+    uint4 ahead[3]; /* single buffer: chunk i of the next row is loaded as soon as step i has used it */
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const uint32_t j = 8u * i + slot;
-        nextv[i] = make_uint4(0, 0, 0, 0);
-        if (j < nblk) nextv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+        ahead[i] = make_uint4(0, 0, 0, 0);
+        if (j < nblk) ahead[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
     }
     for (uint32_t mrow = wg.mcu_row; mrow < row_end; ++mrow, cbase += row_stride) {
-        uint4 curv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) curv[i] = nextv[i];
-        if (mrow + 1 < row_end) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const uint32_t j = 8u * i + slot;
-                if (j < nblk) nextv[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
-            }
-        }
         for (uint32_t r0 = 0; r0 < nblk; r0 += 24) {
-            uint4 rawv[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                rawv[i] = curv[i];
-                if (r0) { /* layouts with more than 24 units per wave and row: loaded in place */
-                    const uint32_t j = r0 + 8u * i + slot;
-                    rawv[i] = make_uint4(0, 0, 0, 0);
-                    if (j < nblk) rawv[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const uint32_t j = r0 + 8u * i + slot;
                 if (r0 + 8u * i >= nblk) break; /* wave-uniform */
                 const bool act = j < nblk;
-                const uint4 raw = rawv[i];
+                uint4 raw = ahead[i];
+                if (r0) { /* layouts with more than 24 units per wave and row: loaded in place */
+                    raw = make_uint4(0, 0, 0, 0);
+                    if (act) raw = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+                } else if (act && mrow + 1 < row_end) {
+                    ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
+                }
                 uint32_t m = 0, b = 0, meta = 0;
                 double col[8], t[8];
                 if (act) {
