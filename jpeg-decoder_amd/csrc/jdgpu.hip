@@ -1308,7 +1308,6 @@ struct jdgpu_batch {
     hipEvent_t ev[JDGPU_NSTAGES + 1];
     float ms[JDGPU_NSTAGES];
     std::vector<uint32_t> status;
-    uint32_t *h_changed; /* pinned */
     int retries;
     bool timed;
 };
@@ -1371,7 +1370,6 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     hipFree(b->d_list_cnt); hipFree(b->d_status); hipFree(b->d_cnt); hipFree(b->d_cp_state); hipFree(b->d_cp_val);
     hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
     hipFree(b->d_rwg); hipFree(b->d_wwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
-    if (b->h_changed) hipHostFree(b->h_changed);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
     jd_plan_free(&b->plan);
@@ -1401,7 +1399,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     jdgpu_batch *b = new jdgpu_batch();
     memset(static_cast<void *>(&b->plan), 0, sizeof b->plan);
     b->flags = flags;
-    b->stream = nullptr; b->h_changed = nullptr; b->retries = 0; b->timed = false;
+    b->stream = nullptr; b->retries = 0; b->timed = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
@@ -1419,7 +1417,6 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
 
     HIPTRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (auto &e : b->ev) HIPTRY(hipEventCreate(&e));
-    HIPTRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_changed), 64));
     TRY(dalloc(&b->d_raw, P.raw_bytes));
     TRY(dalloc(&b->d_clean, P.clean_bytes));
     TRY(dalloc(&b->d_pix, (size_t)P.pix_bytes + 256));
@@ -1538,7 +1535,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
                            b->d_ivl_u, b->d_ivl_seg, b->d_clean);
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
-    if (P.n_hwg) enqueue_huffman(b, true);
+    if (P.n_hwg) { if (int rc = enqueue_huffman(b, true)) return rc; }
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
@@ -1576,7 +1573,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         std::vector<uint32_t> lc(P.n);
         for (uint32_t pass = 0;; ++pass) {
             if (pass > P.n_segs_cap) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
-            enqueue_huffman(b, false);
+            if (int rc = enqueue_huffman(b, false)) return rc;
             HIPCHK(hipMemcpyAsync(lc.data(), b->d_list_cnt + (size_t)(JD_REPAIR_ROUNDS - 1) * P.n, P.n * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             bool clean = true;
@@ -1587,6 +1584,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         launch_pixel(b, s);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
     for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);
