@@ -74,7 +74,8 @@ enum {
 /* stages reported by jdgpu_batch_stage_ms */
 enum {
     JDGPU_STAGE_UNSTUFF = 0,  /* replaces src/bitstream.c:7-18 */
-    JDGPU_STAGE_SYNC = 1,     /* speculative decode + stitching (no counterpart: src/jpeg.c:74-87 is serial) */
+    JDGPU_STAGE_SYNC = 1,     /* start state of every segment: speculative decode, chain check, repair rounds
+                                 (no counterpart: src/jpeg.c:74-87 is serial) */
     JDGPU_STAGE_SCAN = 2,     /* block offsets + DC prediction: src/jpeg.c:73, src/decoding.c:44 */
     JDGPU_STAGE_WRITE = 3,    /* coefficient write: src/decoding.c:40-66 */
     JDGPU_STAGE_PIXEL = 4,    /* src/decoding.c:46,65,68-110 + src/image.c:39-51 */
@@ -123,7 +124,8 @@ void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);       /* device po
 int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
 /* HIP-event milliseconds per stage of the most recent decode (needs JDGPU_PROFILE). */
 int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
-/* number of extra stitching rounds the last decode needed (0 in the common case) */
+/* number of extra repair passes (beyond the built-in rounds) the last decode needed: 0 in the
+ * common case, each one costs a host round trip and a second scan/write/pixel pass */
 int      jdgpu_batch_retries(const jdgpu_batch *b);
 /* development aid: how many segments the start-state repair listed in each of its rounds during
  * the last decode pass (summed over the images); rounds beyond the built-in number read 0 */
