@@ -237,6 +237,47 @@ def test_error_status_matches_oracle(pkg, dec, oracle):
             assert out.status(i) & want[rc], (i, rc, out.status(i))
 
 
+def test_fuzzed_scans_same_outcome_as_oracle(pkg, dec, oracle):
+    """120 seeded corruptions of four fixtures (byte flips, bursts, truncations, inserted 0xFF and
+    marker bytes), decoded as ONE batch together with the intact streams: per image the same
+    outcome class as the oracle -- and where the oracle decodes (a corrupted stream often still
+    parses), the same coefficients, i.e. the same resynchronisation behaviour bit for bit"""
+    rng = np.random.default_rng(2024)
+    bases = [golden_stream(n) for n in ("syn_200x136_420_q50", "syn_200x136_444_q95",
+                                        "ex_no_subsampling_lake", "syn_96x40_422_q80")]
+    files = list(bases)
+    for t in range(120):
+        g = bytearray(bases[t % len(bases)])
+        off = oracle.parse(bytes(g))[1].scan_offset
+        n = len(g) - off - 2
+        kind = t % 5
+        pos = off + int(rng.integers(0, max(1, n)))
+        if kind == 0:
+            g[pos] ^= 1 << int(rng.integers(8))
+        elif kind == 1:
+            ln = int(rng.integers(2, 64))
+            g[pos:pos + ln] = bytes(rng.integers(0, 256, ln, dtype=np.uint8))[:max(0, len(g) - pos)]
+        elif kind == 2:
+            g = g[:pos]
+        elif kind == 3:
+            g[pos:pos] = b"\xff" * int(rng.integers(1, 4))
+        else:
+            g[pos:pos + 2] = bytes([0xFF, 0xD0 + int(rng.integers(8))])
+        files.append(bytes(g))
+    out = dec.decode(files)
+    want = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}
+    classes = {0: 0, -2: 0, -3: 0}
+    for i, f in enumerate(files):
+        rc, info, q = oracle.qcoef(f)
+        classes[rc] = classes.get(rc, 0) + 1
+        if rc == 0:
+            assert out.status(i) == 0, (i, out.status(i))
+            assert np.array_equal(out.qcoef(i).astype(np.int32), q), i
+        else:
+            assert out.status(i) & want[rc], (i, rc, out.status(i))
+    assert classes[0] > 4 and classes[-2] + classes[-3] > 20   # the fuzz reaches both outcomes
+
+
 def test_unsupported_layout_is_reported_not_decoded(pkg, dec):
     d = pkg.parse(golden_stream("syn_8x8_444_q85"))
     d.comp[0].id = 7   # channel = id-1 would be out of range (src/decoding.c:107)
