@@ -279,7 +279,11 @@ static int extend(unsigned size, uint32_t bits) {
     return (bits >> (size - 1)) ? (int)bits : (int)((long)bits - (1L << size) + 1);
 }
 
+/* coefficient positions past 63 met since the library was loaded (test diagnostics only) */
+unsigned long ojpeg_overruns = 0;
+
 /* src/decoding.c:35-66 on quantised values (the multiply by quantTable is applied later) */
+
 static int decode_block(int32_t q[64], const otree *dc, const otree *ac, bitrd *s, int *pred) {
     memset(q, 0, 64 * sizeof *q);
     int size = decode_symbol(dc, s);
@@ -299,7 +303,9 @@ static int decode_block(int32_t q[64], const otree *dc, const otree *ac, bitrd *
         }
         bits = get_bits(s, sz);
         if (s->err) return s->err;
-        if (i < 64) q[i] = extend(sz, bits); /* the reference has no bound check (decoding.c:65) */
+        if (i < 64) q[i] = extend(sz, bits);
+        else ++ojpeg_overruns; /* the reference stores past coeffVector here (decoding.c:65, no bound
+                                  check): undefined behaviour, in practice a stack-protector abort */
     }
     return 0;
 }

@@ -68,6 +68,11 @@ class Oracle:
         a = np.frombuffer(bytes(data), dtype=np.uint8)
         return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
 
+    def overruns(self):
+        """coefficient positions past 63 seen so far: inputs on which the reference itself has
+        undefined behaviour (src/decoding.c:65 has no bound check)"""
+        return C.c_ulong.in_dll(self.lib, "ojpeg_overruns").value
+
     def parse(self, data):
         a, p = self._buf(data)
         info = Info()

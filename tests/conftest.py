@@ -54,3 +54,31 @@ def plain_names():
 def dri_names():
     m = json.load(open(os.path.join(GOLD, "manifest.json")))["entries"]
     return sorted(n for n in m if m[n]["dri"])
+
+
+def fuzzed_streams(oracle, count=120, seed=2024):
+    """the four intact fixtures followed by `count` seeded corruptions of their scans: bit flips,
+    random bursts, truncations, inserted 0xFF bytes, stray RSTn markers"""
+    rng = np.random.default_rng(seed)
+    bases = [golden_stream(n) for n in ("syn_200x136_420_q50", "syn_200x136_444_q95",
+                                        "ex_no_subsampling_lake", "syn_96x40_422_q80")]
+    files = list(bases)
+    for t in range(count):
+        g = bytearray(bases[t % len(bases)])
+        off = oracle.parse(bytes(g))[1].scan_offset
+        n = len(g) - off - 2
+        kind = t % 5
+        pos = off + int(rng.integers(0, max(1, n)))
+        if kind == 0:
+            g[pos] ^= 1 << int(rng.integers(8))
+        elif kind == 1:
+            ln = int(rng.integers(2, 64))
+            g[pos:pos + ln] = bytes(rng.integers(0, 256, ln, dtype=np.uint8))[:max(0, len(g) - pos)]
+        elif kind == 2:
+            g = g[:pos]
+        elif kind == 3:
+            g[pos:pos] = b"\xff" * int(rng.integers(1, 4))
+        else:
+            g[pos:pos + 2] = bytes([0xFF, 0xD0 + int(rng.integers(8))])
+        files.append(bytes(g))
+    return files

@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, all_golden_names, dri_names, golden_arrays, golden_stream, load_pkg, plain_names
+from conftest import (ROOT, all_golden_names, dri_names, fuzzed_streams, golden_arrays, golden_stream,
+                      load_pkg, plain_names)
 
 pytestmark = pytest.mark.gpu
 
@@ -242,28 +243,7 @@ def test_fuzzed_scans_same_outcome_as_oracle(pkg, dec, oracle):
     marker bytes), decoded as ONE batch together with the intact streams: per image the same
     outcome class as the oracle -- and where the oracle decodes (a corrupted stream often still
     parses), the same coefficients, i.e. the same resynchronisation behaviour bit for bit"""
-    rng = np.random.default_rng(2024)
-    bases = [golden_stream(n) for n in ("syn_200x136_420_q50", "syn_200x136_444_q95",
-                                        "ex_no_subsampling_lake", "syn_96x40_422_q80")]
-    files = list(bases)
-    for t in range(120):
-        g = bytearray(bases[t % len(bases)])
-        off = oracle.parse(bytes(g))[1].scan_offset
-        n = len(g) - off - 2
-        kind = t % 5
-        pos = off + int(rng.integers(0, max(1, n)))
-        if kind == 0:
-            g[pos] ^= 1 << int(rng.integers(8))
-        elif kind == 1:
-            ln = int(rng.integers(2, 64))
-            g[pos:pos + ln] = bytes(rng.integers(0, 256, ln, dtype=np.uint8))[:max(0, len(g) - pos)]
-        elif kind == 2:
-            g = g[:pos]
-        elif kind == 3:
-            g[pos:pos] = b"\xff" * int(rng.integers(1, 4))
-        else:
-            g[pos:pos + 2] = bytes([0xFF, 0xD0 + int(rng.integers(8))])
-        files.append(bytes(g))
+    files = fuzzed_streams(oracle)
     out = dec.decode(files)
     want = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}
     classes = {0: 0, -2: 0, -3: 0}
