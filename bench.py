@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", default="rgb", choices=["rgb", "rgba", "planar"],
+                    help="output layout (default: the reference's 3-byte pixel[]; the others are SURVEY 8 row f3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +132,9 @@ def main():
     # c4 with DRI cannot be decoded by the reference; its CPU baseline uses the non-DRI twin shape
     files = make_files(pkg, args.workload, distinct, rank)
     descs = [pkg.parse(f) for f in files]
-    batch = pkg.Batch([descs[i % len(descs)] for i in range(batch_n)], flags=pkg.OUT_RGB | pkg.PROFILE)
+    layout_flag = {"rgb": 0, "rgba": pkg.OUT_4BYTE, "planar": pkg.OUT_PLANAR}[args.layout]
+    px_bytes = 4 if args.layout == "rgba" else 3
+    batch = pkg.Batch([descs[i % len(descs)] for i in range(batch_n)], flags=pkg.OUT_RGB | pkg.PROFILE | layout_flag)
 
     def barrier():
         torch.cuda.synchronize()
@@ -170,7 +174,7 @@ def main():
             "sync": batch.total_scan_bytes,
             "scan": 0,
             "write": batch.total_scan_bytes + coef_b,
-            "pixel": coef_b + pixels * 3,
+            "pixel": coef_b + pixels * px_bytes,
         }
 
         def roof(stage):
@@ -186,7 +190,7 @@ def main():
             try:
                 t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
                 k = t["kernels"].get(r["kernel"])
-                if args.workload == "c3" and k:
+                if args.workload == "c3" and args.layout == "rgb" and k:
                     per_px = (2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024 / (t["images"] * t["pixels_per_image"])
                     r["traffic"] = int(per_px * pixels)
                     r["traffic_source"] = "PMC FETCH_SIZE x2 + WRITE_SIZE (KiB), 256-image launch, scaled per pixel"
@@ -202,6 +206,7 @@ def main():
             "dtype": "u8/i16 entropy decode, f64 IDCT", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": batch_n, "distinct_images": len(files),
                        "pixels_per_step_per_gpu": pixels, "scan_bytes_per_step_per_gpu": batch.total_scan_bytes,
+                       "output_layout": args.layout,
                        "parallelism": f"image-sharded x{world}, no collective"},
             "roofline": with_traffic(roof(dominant)),
             "pixel_stage": with_traffic(roof("pixel")),

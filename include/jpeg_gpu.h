@@ -68,7 +68,12 @@ enum {
     JDGPU_OUT_RGB = 0,        /* fused YCbCr->RGB store: jpeg_read_image + image_ycbcr_to_rgb */
     JDGPU_OUT_YCBCR = 1,      /* what jpeg_read_image alone leaves in the buffer */
     JDGPU_PROFILE = 2,        /* record HIP events around every stage of each decode */
-    JDGPU_HOST_PREP = 4       /* debug: unstuff/split the scan on the host instead of on the GPU */
+    JDGPU_HOST_PREP = 4,      /* debug: unstuff/split the scan on the host instead of on the GPU */
+    /* output layouts other than pixel[] of src/image.h:4-12 (row f3 of SURVEY 8: the 3-byte
+     * interleaved layout is what the reference's callers get; loaders want one of these).  Same
+     * sample values, rows without padding; combine with JDGPU_OUT_RGB or JDGPU_OUT_YCBCR. */
+    JDGPU_OUT_4BYTE = 8,      /* 4 interleaved bytes per pixel, the fourth = 255 (RGBA / YCbCrA) */
+    JDGPU_OUT_PLANAR = 16     /* three planes of width*height bytes, in channel order ([3][H][W]) */
 };
 
 /* stages reported by jdgpu_batch_stage_ms */
@@ -94,6 +99,14 @@ const char *jdgpu_last_error(void);          /* thread-local text of the last fa
  * points into `file`.  0 or JDGPU_ERR_HEADER / JDGPU_ERR_UNSUPPORTED. */
 int jdgpu_parse_file(const uint8_t *file, size_t len, jdgpu_image_desc *desc);
 
+/* The same over n files on `threads` host threads (0 = one per available core, at most 16).
+ * status (may be NULL) receives the per-file return code; a rejected file leaves a zeroed
+ * descriptor, which jdgpu_batch_create carries as JDGPU_IMG_UNSUPPORTED without decoding it.
+ * Returns the number of rejected files, or JDGPU_ERR_ARG.  (Row f1 of SURVEY 8: the header loop
+ * of src/jpeg.c:23-58 is serial per file and independent between files.) */
+long jdgpu_parse_files(const uint8_t *const *files, const size_t *lens, size_t n,
+                       jdgpu_image_desc *descs, int *status, unsigned threads);
+
 /* ---- batched decode: replaces jpeg_read_image (src/jpeg.c:63-88) and, with JDGPU_OUT_RGB,
  *      image_ycbcr_to_rgb (src/image.c:39-51), for n independent images ---------------------- */
 
@@ -116,9 +129,14 @@ uint64_t jdgpu_batch_total_pixels(const jdgpu_batch *b);            /* sum of wi
 uint64_t jdgpu_batch_total_blocks(const jdgpu_batch *b);            /* 8x8 data units */
 uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b);
 size_t   jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i);
-/* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14) */
+/* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14); with JDGPU_OUT_4BYTE or
+ * JDGPU_OUT_PLANAR the layout chosen at creation (jdgpu_batch_pixel_bytes tells the size) */
 int      jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst);
-void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);       /* device pointer, same layout */
+size_t   jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i);
+/* device pointer, same layout; image i starts on a 256-byte boundary, and images of a batch lie
+ * one after the other -- a batch of equal-sized images whose size is a multiple of 256 bytes
+ * (1920x1080: yes) is one dense [n][...] array starting at image 0 */
+void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);
 /* Quantised coefficients, [nblocks][64] int16 in ZIGZAG order, DC un-differenced, decode order
  * (the values src/decoding.c:44,65 computes before the multiply by the quantisation table). */
 int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);

@@ -20,15 +20,15 @@ OK = 0
 ERR_HEADER = -1
 ERR_NO_DEVICE = -10
 IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
-OUT_RGB, OUT_YCBCR, PROFILE, HOST_PREP = 0, 1, 2, 4
+OUT_RGB, OUT_YCBCR, PROFILE, HOST_PREP, OUT_4BYTE, OUT_PLANAR = 0, 1, 2, 4, 8, 16
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 
 EXPORTS = [
-    "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_parse_file",
+    "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_parse_file", "jdgpu_parse_files",
     "jdgpu_batch_create", "jdgpu_batch_decode", "jdgpu_batch_sync", "jdgpu_batch_destroy",
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
-    "jdgpu_batch_read_pixels", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
+    "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb",
     "jdgpu_host_lut_lookup", "jdgpu_host_unstuff", "jdgpu_batch_debug_segments",
     "jdgpu_segment_bytes",
@@ -70,10 +70,22 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise JpegError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
                         "(make -C jpeg-decoder_amd); there is no CPU fallback")
+    # One HIP runtime per process.  The torch wheel carries its own libamdhip64.so.7 + HSA runtime;
+    # whichever copy is loaded first serves every later user of that soname.  Loaded after
+    # /opt/rocm's (which this library would pull in on its own), torch finds no GPU -- so where
+    # torch is installed it goes first and the library binds to its runtime (measured: same
+    # kernel times either way).  Without torch the library loads /opt/rocm's runtime as linked.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
     L.jdgpu_last_error.restype = C.c_char_p
     L.jdgpu_parse_file.argtypes = [vp, sz, C.POINTER(ImageDesc)]
+    L.jdgpu_parse_files.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(ImageDesc),
+                                    C.POINTER(C.c_int), C.c_uint]
+    L.jdgpu_parse_files.restype = C.c_long
     L.jdgpu_batch_create.argtypes = [C.POINTER(ImageDesc), sz, C.c_uint, C.POINTER(vp)]
     for f in ("jdgpu_batch_decode", "jdgpu_batch_sync"):
         getattr(L, f).argtypes = [vp]
@@ -89,6 +101,8 @@ def lib():
     L.jdgpu_batch_image_blocks.argtypes = [vp, sz]
     L.jdgpu_batch_image_blocks.restype = sz
     L.jdgpu_batch_read_pixels.argtypes = [vp, sz, vp]
+    L.jdgpu_batch_pixel_bytes.argtypes = [vp, sz]
+    L.jdgpu_batch_pixel_bytes.restype = sz
     L.jdgpu_batch_device_pixels.argtypes = [vp, sz]
     L.jdgpu_batch_device_pixels.restype = vp
     L.jdgpu_batch_read_coefficients.argtypes = [vp, sz, vp]
@@ -123,13 +137,55 @@ def parse(data):
     return d
 
 
+class DescArray:
+    """n descriptors in one ctypes array (what jdgpu_batch_create takes) + the file buffers their
+    scan pointers alias + the per-file parse status."""
+
+    def __init__(self, arr, n, keep, status):
+        self.arr, self.n, self._keep, self.status = arr, n, keep, status
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return self.arr[i]
+
+    def __iter__(self):
+        return (self.arr[i] for i in range(self.n))
+
+
+def parse_many(files, threads=0, strict=True):
+    """jdgpu_parse_files: the headers of many files on `threads` host threads (0 = per core).
+    strict: raise on the first rejected header, as parse() does; otherwise rejected files keep a
+    zeroed descriptor (decoded as IMG_UNSUPPORTED) and .status holds the codes."""
+    L = lib()
+    n = len(files)
+    keep = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * max(1, n))(*[k.ctypes.data if k.size else None for k in keep])
+    lens = (C.c_size_t * max(1, n))(*[k.size for k in keep])
+    arr = (ImageDesc * max(1, n))()
+    status = (C.c_int * max(1, n))()
+    bad = L.jdgpu_parse_files(ptrs, lens, n, arr, status, threads)
+    if bad < 0:
+        raise _err(L, "jdgpu_parse_files", bad)
+    if bad and strict:
+        i = next(i for i in range(n) if status[i])
+        raise JpegError(f"header of file {i} rejected ({status[i]}); {bad} of {n} rejected")
+    return DescArray(arr, n, keep, list(status[:n]))
+
+
 class Batch:
     """A decode batch resident on one GPU (jdgpu_batch)."""
 
     def __init__(self, descs, flags=OUT_RGB):
         L = self._L = lib()
-        self.descs = list(descs)
-        arr = (ImageDesc * max(1, len(self.descs)))(*self.descs)
+        if isinstance(descs, DescArray):
+            self.descs, arr = descs, descs.arr
+        else:
+            self.descs = list(descs)
+            arr = (ImageDesc * max(1, len(self.descs)))(*self.descs)
         h = C.c_void_p()
         rc = L.jdgpu_batch_create(arr, len(self.descs), flags, C.byref(h))
         if rc:
@@ -155,9 +211,16 @@ class Batch:
     def status(self, i):
         return int(self._L.jdgpu_batch_status(self._h, i))
 
-    def pixels(self, i):
+    def shape(self, i):
+        """array shape of image i in the batch's output layout"""
         w, h = self.dims[i]
-        out = np.empty((h, w, 3), np.uint8)
+        if self.flags & OUT_PLANAR:
+            return (3, h, w)
+        return (h, w, 4 if self.flags & OUT_4BYTE else 3)
+
+    def pixels(self, i):
+        out = np.empty(self.shape(i), np.uint8)
+        assert out.nbytes == self._L.jdgpu_batch_pixel_bytes(self._h, i)
         rc = self._L.jdgpu_batch_read_pixels(self._h, i, out.ctypes.data)
         if rc:
             raise _err(self._L, "jdgpu_batch_read_pixels", rc)
@@ -219,6 +282,21 @@ class Batch:
     def device_pixels(self, i):
         return int(self._L.jdgpu_batch_device_pixels(self._h, i) or 0)
 
+    def tensor(self, i):
+        """image i as a torch uint8 tensor on the GPU that ALIASES the batch's output buffer (no
+        copy; valid until the batch is closed or decoded again; synchronise first)."""
+        return _device_view(self, self.device_pixels(i), self.shape(i))
+
+    def tensor_all(self):
+        """the whole batch as one [n, ...] tensor aliasing the output buffer; only for batches of
+        equal-sized images whose byte size is a multiple of 256 (images start on 256 bytes)"""
+        if self.n == 0 or len(set(self.dims)) != 1:
+            raise JpegError("tensor_all needs a non-empty batch of equal-sized images")
+        nbytes = int(np.prod(self.shape(0)))
+        if self.n > 1 and self.device_pixels(1) - self.device_pixels(0) != nbytes:
+            raise JpegError(f"images of {nbytes} bytes are padded to 256-byte starts: not one dense array")
+        return _device_view(self, self.device_pixels(0), (self.n,) + self.shape(0))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.jdgpu_batch_destroy(self._h)
@@ -229,6 +307,23 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class _DeviceArray:
+    """__cuda_array_interface__ over a region of a batch's output buffer (keeps the batch alive)"""
+
+    def __init__(self, owner, ptr, shape):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def _device_view(owner, ptr, shape):
+    import torch
+    if not ptr:
+        raise JpegError("the batch has no device output buffer")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(_DeviceArray(owner, ptr, shape), device=dev)
 
 
 class Decoder:
@@ -242,7 +337,7 @@ class Decoder:
         self.device = device
 
     def batch(self, files, flags=OUT_RGB):
-        return Batch([parse(f) for f in files], flags)
+        return Batch(parse_many(files), flags)
 
     def decode(self, files, flags=OUT_RGB):
         return self.batch(files, flags).decode()

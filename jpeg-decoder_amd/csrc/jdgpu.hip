@@ -1023,11 +1023,12 @@ __device__ __forceinline__ int green_fix(const ChromaTerms &t, int Y) {
 
 __device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
 
-/* 4 pixels that share their chroma in pairs (4:2:0) or not (4:4:4) -> 12 output bytes */
-struct Px4 { uint32_t d0, d1, d2; };
+/* 4 pixels that share their chroma in pairs (4:2:0) or not (4:4:4) -> 12 channel values,
+ * o[3 * pixel + channel] */
+struct Px4 { uint32_t o[12]; };
 template <bool OUT_YCBCR>
 __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const uint32_t crv[4], int nterms) {
-    uint32_t o[12];
+    Px4 r;
     ChromaTerms ct[4];
     if (!OUT_YCBCR) {
         ct[0] = chroma_terms((int)cbv[0], (int)crv[0]);
@@ -1046,27 +1047,55 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int Y = (int)((y4 >> (8 * i)) & 255u);
-        if (OUT_YCBCR) { o[3 * i] = (uint32_t)Y; o[3 * i + 1] = cbv[i]; o[3 * i + 2] = crv[i]; }
+        if (OUT_YCBCR) { r.o[3 * i] = (uint32_t)Y; r.o[3 * i + 1] = cbv[i]; r.o[3 * i + 2] = crv[i]; }
         else {
-            o[3 * i] = clamp255(Y + ct[i].dr);
-            o[3 * i + 1] = clamp255(Y + ct[i].dg - (any_exc ? green_fix(ct[i], Y) : 0));
-            o[3 * i + 2] = clamp255(Y + ct[i].db);
+            r.o[3 * i] = clamp255(Y + ct[i].dr);
+            r.o[3 * i + 1] = clamp255(Y + ct[i].dg - (any_exc ? green_fix(ct[i], Y) : 0));
+            r.o[3 * i + 2] = clamp255(Y + ct[i].db);
         }
     }
-    Px4 r;
-    r.d0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-    r.d1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
-    r.d2 = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
     return r;
 }
 
-__device__ __forceinline__ void store_px4(uint8_t *out, size_t off, const Px4 &v, bool aligned, uint32_t npx) {
-    if (aligned) {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out + off);
-        dst[0] = v.d0; dst[1] = v.d1; dst[2] = v.d2;
+/* output layouts (JDGPU_OUT_* in include/jpeg_gpu.h).  The lane's 4 pixels start at column x
+ * (a multiple of 4) of row y; npx of them lie inside the image. */
+#define JD_FMT_3 0u       /* pixel[] of src/image.h:4-12: 3 interleaved bytes */
+#define JD_FMT_4 1u       /* 4 interleaved bytes, the fourth 255 */
+#define JD_FMT_PLANAR 2u  /* three planes of width*height bytes */
+template <uint32_t FMT>
+__device__ __forceinline__ void store_px4(uint8_t *out, uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                                          const Px4 &v, bool aligned, uint32_t npx) {
+    const uint32_t *o = v.o;
+    const size_t at = (size_t)y * W + x;
+    if (FMT == JD_FMT_4) {
+        /* 16 bytes per lane, always aligned (x is a multiple of 4, images start on 256 bytes) */
+        uint32_t p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = o[3 * i] | (o[3 * i + 1] << 8) | (o[3 * i + 2] << 16) | 0xFF000000u;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + at * 4);
+        if (npx == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
+        else
+            for (uint32_t i = 0; i < npx; ++i) dst[i] = p[i];
+    } else if (FMT == JD_FMT_PLANAR) {
+        const size_t plane = (size_t)W * H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t w = o[c] | (o[3 + c] << 8) | (o[6 + c] << 16) | (o[9 + c] << 24);
+            uint8_t *dst = out + c * plane + at;
+            if (aligned) *reinterpret_cast<uint32_t *>(dst) = w;       /* W % 4 == 0 */
+            else
+                for (uint32_t i = 0; i < npx; ++i) dst[i] = (uint8_t)(w >> (8 * i));
+        }
     } else {
-        const uint32_t w[3] = {v.d0, v.d1, v.d2};
-        for (uint32_t i = 0; i < npx * 3; ++i) out[off + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        const uint32_t w[3] = {o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24),
+                               o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24),
+                               o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24)};
+        if (aligned) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(out + at * 3);
+            dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
+        } else {
+            for (uint32_t i = 0; i < npx * 3; ++i) out[at * 3 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        }
     }
 }
 
@@ -1092,9 +1121,9 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t off, const Px4 &v
  *   phase 2: 4 pixels per lane (x 2 rows when chroma is shared vertically): gather Y/Cb/Cr
  *            (replicated chroma), colour transform, one 12-byte store; 16 lanes cover 192
  *            contiguous bytes of an output row.
- * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces).
+ * OUT_YCBCR leaves YCbCr in the buffer (what jpeg_read_image produces); FMT: output layout.
  */
-template <bool OUT_YCBCR, uint32_t MODE>
+template <bool OUT_YCBCR, uint32_t MODE, uint32_t FMT>
 __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__restrict__ imgs,
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
@@ -1229,7 +1258,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         if (r < rows) {
                             uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
                             Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
-                            store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                            store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
                         }
                     }
                 }
@@ -1241,7 +1270,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
                     const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
                     Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
-                    store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                    store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
                 }
             } else {
                 /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
@@ -1264,7 +1293,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     }
                     uint32_t y4 = sm[0][0] | (sm[0][1] << 8) | (sm[0][2] << 16) | (sm[0][3] << 24);
                     Px4 v = colour4<OUT_YCBCR>(y4, sm[1], sm[2], 4);
-                    store_px4(out, ((size_t)(y0 + r) * W + x) * 3, v, aligned, npx);
+                    store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
                 }
             }
         }
@@ -1394,6 +1423,10 @@ static int stage_reserve(size_t bytes) {
 extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out) {
     if (!out || (!descs && n)) { snprintf(g_err, sizeof g_err, "null argument"); return JDGPU_ERR_ARG; }
     *out = nullptr;
+    if ((flags & JDGPU_OUT_4BYTE) && (flags & JDGPU_OUT_PLANAR)) {
+        snprintf(g_err, sizeof g_err, "JDGPU_OUT_4BYTE and JDGPU_OUT_PLANAR exclude each other");
+        return JDGPU_ERR_ARG;
+    }
     int rc = ensure_device();
     if (rc) return rc;
     jdgpu_batch *b = new jdgpu_batch();
@@ -1409,7 +1442,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t0 = now();
-    TRY(jd_plan_build(descs, n, &b->plan, g_err, sizeof g_err));
+    TRY(jd_plan_build(descs, n, (flags & JDGPU_OUT_4BYTE) ? 4u : 3u, &b->plan, g_err, sizeof g_err));
     jd_plan &P = b->plan;
     if (trace) { fprintf(stderr, "[jdgpu] plan %.1f ms\n", now() - t0); t0 = now(); }
     b->status.assign(n, 0);
@@ -1475,23 +1508,29 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     return JDGPU_OK;
 }
 
-template <bool OUT_YCBCR>
+template <bool OUT_YCBCR, uint32_t FMT>
 static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
     jd_plan &P = b->plan;
     const dim3 block(64 * JD_PIX_WAVES);
     const uint32_t *f = P.pwg_mode_first;
     if (f[JD_PIX_GENERIC + 1] > f[JD_PIX_GENERIC])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_GENERIC>), dim3(f[JD_PIX_GENERIC + 1] - f[JD_PIX_GENERIC]), block, 0, st,
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_GENERIC, FMT>), dim3(f[JD_PIX_GENERIC + 1] - f[JD_PIX_GENERIC]), block, 0, st,
                            b->d_img, b->d_pwg + f[JD_PIX_GENERIC], b->d_coef, b->d_pix, P.pix_rows);
     if (f[JD_PIX_420 + 1] > f[JD_PIX_420])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_420>), dim3(f[JD_PIX_420 + 1] - f[JD_PIX_420]), block, 0, st,
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_420, FMT>), dim3(f[JD_PIX_420 + 1] - f[JD_PIX_420]), block, 0, st,
                            b->d_img, b->d_pwg + f[JD_PIX_420], b->d_coef, b->d_pix, P.pix_rows);
     if (f[JD_PIX_444 + 1] > f[JD_PIX_444])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_444>), dim3(f[JD_PIX_444 + 1] - f[JD_PIX_444]), block, 0, st,
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_444, FMT>), dim3(f[JD_PIX_444 + 1] - f[JD_PIX_444]), block, 0, st,
                            b->d_img, b->d_pwg + f[JD_PIX_444], b->d_coef, b->d_pix, P.pix_rows);
 }
+template <bool OUT_YCBCR>
+static void launch_pixel_formats(jdgpu_batch *b, hipStream_t st) {
+    if (b->flags & JDGPU_OUT_4BYTE) launch_pixel_modes<OUT_YCBCR, JD_FMT_4>(b, st);
+    else if (b->flags & JDGPU_OUT_PLANAR) launch_pixel_modes<OUT_YCBCR, JD_FMT_PLANAR>(b, st);
+    else launch_pixel_modes<OUT_YCBCR, JD_FMT_3>(b, st);
+}
 static void launch_pixel(jdgpu_batch *b, hipStream_t st) {
-    if (b->flags & JDGPU_OUT_YCBCR) launch_pixel_modes<true>(b, st); else launch_pixel_modes<false>(b, st);
+    if (b->flags & JDGPU_OUT_YCBCR) launch_pixel_formats<true>(b, st); else launch_pixel_formats<false>(b, st);
 }
 
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
@@ -1627,8 +1666,13 @@ extern "C" void *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i) {
 extern "C" int jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst) {
     if (!b || i >= b->plan.n || !dst) return JDGPU_ERR_ARG;
     const jd_image &im = b->plan.img[i];
-    HIPCHK(hipMemcpy(dst, b->d_pix + im.pix_off, (size_t)im.width * im.height * 3, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, b->d_pix + im.pix_off, (size_t)im.width * im.height * b->plan.px_bytes, hipMemcpyDeviceToHost));
     return JDGPU_OK;
+}
+
+extern "C" size_t jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i) {
+    if (!b || i >= b->plan.n) return 0;
+    return (size_t)b->plan.img[i].width * b->plan.img[i].height * b->plan.px_bytes;
 }
 
 extern "C" int jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst) {

@@ -150,9 +150,10 @@ void jd_plan_gather(jd_plan *P, const jdgpu_image_desc *descs, size_t n) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err, size_t errlen) {
+int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd_plan *P, char *err, size_t errlen) {
     memset(P, 0, sizeof *P);
     P->n = n;
+    P->px_bytes = px_bytes;
     P->img = calloc(n ? n : 1, sizeof *P->img);
     P->luts = calloc((n ? n : 1) * JD_LUT_SLOTS, sizeof *P->luts);
     if (!P->img || !P->luts) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
@@ -179,7 +180,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, jd_plan *P, char *err
         im->width = d->width; im->height = d->height;
         im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
         im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
-        pix += align_up((size_t)d->width * d->height * 3, 256);
+        pix += align_up((size_t)d->width * d->height * px_bytes, 256);
         P->total_pixels += (uint64_t)d->width * d->height;
         if (!ok) { /* marked unsupported: no segments, no work-groups, pixels stay zero */
             im->ncomp = 0;

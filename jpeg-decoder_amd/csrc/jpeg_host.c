@@ -237,6 +237,49 @@ int jdgpu_parse_file(const uint8_t *file, size_t len, jdgpu_image_desc *desc) {
     return rc ? JDGPU_ERR_HEADER : JDGPU_OK;
 }
 
+/* Many files at once, split over host threads: one core parses ~27 us per file (tree build +
+ * flatten), which for a 4096-image batch is three times its GPU decode time. */
+#include <pthread.h>
+#include <unistd.h>
+typedef struct {
+    const uint8_t *const *files; const size_t *lens; jdgpu_image_desc *descs; int *status;
+    size_t i0, i1, failed;
+} parse_job;
+static void *parse_run(void *arg) {
+    parse_job *j = arg;
+    for (size_t i = j->i0; i < j->i1; ++i) {
+        int rc = jdgpu_parse_file(j->files[i], j->lens[i], &j->descs[i]);
+        if (rc) { memset(&j->descs[i], 0, sizeof j->descs[i]); ++j->failed; }
+        if (j->status) j->status[i] = rc;
+    }
+    return NULL;
+}
+long jdgpu_parse_files(const uint8_t *const *files, const size_t *lens, size_t n,
+                       jdgpu_image_desc *descs, int *status, unsigned threads) {
+    if ((!files || !lens || !descs) && n) return JDGPU_ERR_ARG;
+    enum { MAXT = 64 };
+    if (threads == 0) {
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        threads = cpus < 1 ? 1 : cpus > 16 ? 16 : (unsigned)cpus; /* the GPU boxes give a process 16 */
+    }
+    if (threads > MAXT) threads = MAXT;
+    if (threads > n / 32 + 1) threads = (unsigned)(n / 32 + 1);  /* a thread start costs ~ a few parses */
+    parse_job job[MAXT];
+    pthread_t th[MAXT];
+    int running[MAXT];
+    for (unsigned t = 0; t < threads; ++t) {
+        job[t] = (parse_job){files, lens, descs, status, n * t / threads, n * (t + 1) / threads, 0};
+        running[t] = t + 1 < threads && pthread_create(&th[t], NULL, parse_run, &job[t]) == 0;
+        if (!running[t]) parse_run(&job[t]); /* the last share, and any thread that would not start */
+    }
+    size_t failed = 0;
+    for (unsigned t = 0; t < threads; ++t) {
+        if (running[t]) pthread_join(th[t], NULL);
+        failed += job[t].failed;
+    }
+    return (long)failed;
+}
+
 /* ---- the decode entry points ---------------------------------------------------------------------- */
 
 static void die(const char *msg) { /* src/macros.h:8 */

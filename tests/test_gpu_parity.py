@@ -258,6 +258,64 @@ def test_fuzzed_scans_same_outcome_as_oracle(pkg, dec, oracle):
     assert classes[0] > 4 and classes[-2] + classes[-3] > 20   # the fuzz reaches both outcomes
 
 
+@pytest.mark.parametrize("name", ["syn_200x136_420_q50", "syn_200x136_444_q95", "syn_96x40_422_q80",
+                                  "syn_72x96_440_q75", "ex_no_subsampling_lake"])
+def test_output_layouts_hold_the_same_samples(pkg, dec, name):
+    """JDGPU_OUT_4BYTE / JDGPU_OUT_PLANAR: the bytes of the pixel[] layout
+    (which the tests above pin to the reference), rearranged; bit-exact, RGB and YCbCr"""
+    data = golden_stream(name)
+    for base in (pkg.OUT_RGB, pkg.OUT_YCBCR):
+        ref = dec.decode([data], base).pixels(0)
+        four = dec.decode([data], base | pkg.OUT_4BYTE).pixels(0)
+        assert four.shape == ref.shape[:2] + (4,)
+        assert np.array_equal(four[..., :3], ref) and (four[..., 3] == 255).all()
+        planar = dec.decode([data], base | pkg.OUT_PLANAR).pixels(0)
+        assert planar.shape == (3,) + ref.shape[:2]
+        assert np.array_equal(planar, ref.transpose(2, 0, 1))
+
+
+def test_output_layouts_ragged_widths_mixed_batch(pkg, dec, oracle):
+    """widths that are not multiples of 4 (the lane's 4-pixel store is cut), odd heights, 4:4:4
+    and 4:2:0 in one batch, every layout against the oracle's RGB"""
+    files = [pkg.synth.make_jpeg(w, h, seed=7 + w, quality=80, subsamp=ss)
+             for (w, h, ss) in ((37, 21, 0), (130, 17, 0), (66, 34, 1), (1, 1, 0), (258, 9, 0), (64, 48, 1))]
+    want = []
+    for f in files:
+        rc, rgb = oracle.rgb(f)
+        assert rc == 0
+        want.append(rgb)
+    for flags, view in ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_4BYTE, lambda a: a[..., :3]),
+                        (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0))):
+        out = dec.decode(files, flags)
+        for i in range(len(files)):
+            assert out.status(i) == 0
+            assert np.array_equal(view(out.pixels(i)), want[i]), (flags, i)
+    with pytest.raises(pkg.JpegError):
+        dec.decode(files, pkg.OUT_4BYTE | pkg.OUT_PLANAR)
+
+
+def test_torch_views_alias_the_output(pkg, dec):
+    """Batch.tensor / tensor_all: zero-copy uint8 tensors over the batch's device buffer"""
+    import torch
+    files = [pkg.synth.make_jpeg(64, 48, seed=s, quality=85, subsamp=1) for s in (1, 2, 3)]
+    for flags in (pkg.OUT_RGB, pkg.OUT_PLANAR, pkg.OUT_4BYTE):
+        out = dec.decode(files, flags)
+        t = out.tensor(1)
+        assert t.is_cuda and t.dtype == torch.uint8 and tuple(t.shape) == out.shape(1)
+        assert t.data_ptr() == out.device_pixels(1)
+        assert np.array_equal(t.cpu().numpy(), out.pixels(1))
+        allt = out.tensor_all()     # 64*48*3 = 9216 bytes = 36 * 256: dense
+        assert tuple(allt.shape) == (3,) + out.shape(0)
+        for i in range(3):
+            assert np.array_equal(allt[i].cpu().numpy(), out.pixels(i))
+        # a consumer's op runs straight on the decoder's output
+        assert float(allt.float().mean()) == pytest.approx(float(np.mean([out.pixels(i) for i in range(3)])), rel=1e-6)
+    ragged = dec.decode([golden_stream("syn_200x136_420_q50")] * 2)   # 81 600 bytes: padded starts
+    with pytest.raises(pkg.JpegError):
+        ragged.tensor_all()
+    assert np.array_equal(ragged.tensor(1).cpu().numpy(), ragged.pixels(1))
+
+
 def test_unsupported_layout_is_reported_not_decoded(pkg, dec):
     d = pkg.parse(golden_stream("syn_8x8_444_q85"))
     d.comp[0].id = 7   # channel = id-1 would be out of range (src/decoding.c:107)

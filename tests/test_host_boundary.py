@@ -99,6 +99,37 @@ def test_header_rejections(pkg, oracle):
             pkg.parse(c)
 
 
+@pytest.mark.parametrize("threads", [0, 1, 5])
+def test_threaded_parse_equals_single(pkg, threads):
+    """jdgpu_parse_files over all fixtures (repeated: 300+ files, so several threads run) ==
+    jdgpu_parse_file one at a time, descriptor bytes and status; rejected files in between leave a
+    zeroed descriptor and are counted"""
+    names = all_golden_names()
+    good = [golden_stream(n) for n in names] * 20
+    bad = bytearray(good[0]); bad[1] = 0xD9
+    files = good[:7] + [bytes(bad)] + good[7:100] + [b""] + good[100:] + [good[3][:40]]
+    got = pkg.parse_many(files, threads=threads, strict=False)
+    assert len(got) == len(files)
+    rejected = [i for i, st in enumerate(got.status) if st]
+    assert rejected == [7, 101, len(files) - 1]
+    assert all(got.status[i] == pkg.ERR_HEADER for i in rejected)
+    size = C.sizeof(pkg.ImageDesc)
+    for i, f in enumerate(files):
+        raw = C.string_at(C.addressof(got[i]), size)
+        if i in rejected:
+            assert raw == bytes(size)
+            continue
+        one = pkg.parse(f)
+        assert one.scan_len == got[i].scan_len and got[i].scan_len > 0
+        # everything but the scan pointer (first 8 bytes: each call aliases its own copy)
+        assert raw[8:] == C.string_at(C.addressof(one), size)[8:]
+        off = len(f) - got[i].scan_len
+        assert C.string_at(got[i].scan, 16) == f[off:off + 16]
+    with pytest.raises(pkg.JpegError):
+        pkg.parse_many(files, threads=threads)
+    assert len(pkg.parse_many([], threads=threads)) == 0
+
+
 def _canonical_decode(counts, symbols, v16):
     """bit-by-bit canonical walk (the tree of src/hufftree.c:46-59 as first/count per length)"""
     code, first, k = 0, 0, 0

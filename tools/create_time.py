@@ -10,6 +10,15 @@ files = bench.make_files(pkg, "c3", 64, 0)
 dec = pkg.Decoder(0)
 t = time.perf_counter(); descs = [pkg.parse(f) for f in files]; tp = (time.perf_counter() - t) / len(files)
 use = [descs[i % 64] for i in range(4096)]
+# the headers of 4096 files through jdgpu_parse_files (C call only; the arrays are built before)
+import ctypes as C, numpy as np
+L = pkg.lib()
+keep = [np.frombuffer(files[i % 64], dtype=np.uint8) for i in range(4096)]
+ptrs = (C.c_void_p * 4096)(*[k.ctypes.data for k in keep]); lens = (C.c_size_t * 4096)(*[k.size for k in keep])
+arr = (pkg.ImageDesc * 4096)()
+for th in (1, 4, 8, 16, 0):
+    t = time.perf_counter(); bad = L.jdgpu_parse_files(ptrs, lens, 4096, arr, None, th); tt = time.perf_counter() - t
+    print(f"jdgpu_parse_files(4096 files, threads={th}): {tt*1e3:.1f} ms, {bad} rejected")
 for attempt in ("first", "second"):
     t = time.perf_counter(); b = pkg.Batch(use); tc = time.perf_counter() - t
     b.decode()
