@@ -1285,9 +1285,10 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const uint8_t *tp = &tile[c * PLANE_BYTES + (r >> vs[c]) * PIX_ROW];
+                        const bool absent = (uint32_t)c >= im.ncomp; /* grayscale: neutral chroma */
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            uint32_t v = tp[(4u * g + i) >> hs[c]];
+                            uint32_t v = absent ? 128u : tp[(4u * g + i) >> hs[c]];
                             if (ch[c] == 0) sm[0][i] = v; else if (ch[c] == 1) sm[1][i] = v; else sm[2][i] = v;
                         }
                     }

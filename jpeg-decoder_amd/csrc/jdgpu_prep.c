@@ -165,9 +165,13 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
     for (size_t i = 0; i < n; ++i) {
         const jdgpu_image_desc *d = &descs[i];
         jd_image *im = &P->img[i];
-        int ok = d->ncomp == 3 && d->width && d->height && d->scan_len < 0xFFFFFF00u;
+        /* three components, or one (grayscale, SURVEY 8f2: the absent channels read 128) */
+        const unsigned nc = d->ncomp == 1 ? 1u : 3u;
+        int ok = (d->ncomp == 3 || d->ncomp == 1) && d->width && d->height && d->scan_len < 0xFFFFFF00u;
+        if (d->ncomp == 1 && (d->comp[0].H != 1 || d->comp[0].V != 1)) ok = 0; /* src/jpeg.c:80-81 would walk
+                                                                                  H x V units per "MCU" */
         unsigned seen = 0, maxH = 0, maxV = 0;
-        for (unsigned c = 0; ok && c < 3; ++c) {
+        for (unsigned c = 0; ok && c < nc; ++c) {
             unsigned id = d->comp[c].id;
             if (id < 1 || id > 3 || (seen >> id & 1)) ok = 0; /* channel = id-1, SURVEY 8(c) */
             seen |= 1u << id;
@@ -186,11 +190,15 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
             im->ncomp = 0;
             continue;
         }
-        im->ncomp = 3; im->maxH = (uint8_t)maxH; im->maxV = (uint8_t)maxV;
+        im->ncomp = (uint8_t)nc; im->maxH = (uint8_t)maxH; im->maxV = (uint8_t)maxV;
+        for (unsigned c = nc; c < 3; ++c) { /* placeholders the pixel kernel never samples */
+            im->comp_H[c] = 1; im->comp_V[c] = 1; im->comp_tq[c] = 0;
+            im->comp_chan[c] = (uint8_t)((d->comp[0].id - 1 + c) % 3);
+        }
         /* lookup tables: slot per distinct (class,id) in order of first use */
         int slot_of[2][4]; memset(slot_of, -1, sizeof slot_of);
         unsigned nslots = 0, b = 0;
-        for (unsigned c = 0; c < 3; ++c) {
+        for (unsigned c = 0; c < nc; ++c) {
             unsigned td = d->comp[c].Td, ta = d->comp[c].Ta;
             if (slot_of[0][td] < 0) {
                 slot_of[0][td] = (int)nslots;
@@ -213,7 +221,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         if (!ok) { im->ncomp = 0; continue; }
         im->bpm = (uint8_t)b;
         {
-            int std_ids = d->comp[0].id == 1 && d->comp[1].id == 2 && d->comp[2].id == 3;
+            int std_ids = nc == 3 && d->comp[0].id == 1 && d->comp[1].id == 2 && d->comp[2].id == 3;
             int c11 = d->comp[1].H == 1 && d->comp[1].V == 1 && d->comp[2].H == 1 && d->comp[2].V == 1;
             im->pix_mode = JD_PIX_GENERIC;
             if (std_ids && c11 && d->comp[0].H == 2 && d->comp[0].V == 2) im->pix_mode = JD_PIX_420;

@@ -309,7 +309,7 @@ void jpeg_read_image(pixel *img, const jpeg_info *info, const scan_info *scanInf
     if (!rc) rc = jdgpu_batch_sync(b);
     if (rc) die(jdgpu_last_error());
     uint32_t st = jdgpu_batch_status(b, 0);
-    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components, ids 1..3, sampling factors 1 or 2).");
+    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components or 1, ids 1..3, sampling factors 1 or 2).");
     if (st & JDGPU_IMG_NOSYMBOL) die("Could not find next symbol in huffnode."); /* src/hufftree.c:69,72 */
     if (st & JDGPU_IMG_EOF) die("Reached end of file.");                         /* src/bitstream.c:17 */
     if (jdgpu_batch_read_pixels(b, 0, img)) die(jdgpu_last_error());

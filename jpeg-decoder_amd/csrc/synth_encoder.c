@@ -165,7 +165,7 @@ static void scale_q(const uint8_t base[64], int quality, uint8_t out[64]) {
 
 /*
  * Encode interleaved RGB (w*h*3).  subsamp: 0 = 4:4:4, 1 = 4:2:0, 2 = 4:2:2 (luma 2x1),
- * 3 = 4:4:0 (luma 1x2).  restart_mcus: 0 = no DRI.
+ * 3 = 4:4:0 (luma 1x2), 4 = grayscale (one component, id 1, luma only).  restart_mcus: 0 = no DRI.
  * Returns the number of bytes the stream needs; if it exceeds cap the buffer content is
  * undefined (call again with a bigger buffer).
  */
@@ -202,16 +202,20 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
     put8(&o, 0); for (int k = 0; k < 64; ++k) put8(&o, ql[ZZ[k]]);
     put8(&o, 1); for (int k = 0; k < 64; ++k) put8(&o, qc[ZZ[k]]);
     /* SOF0 */
-    put16(&o, 0xFFC0); put16(&o, 8 + 9); put8(&o, 8); put16(&o, (unsigned)h); put16(&o, (unsigned)w); put8(&o, 3);
+    const int gray = subsamp == 4, nc = gray ? 1 : 3;
+    put16(&o, 0xFFC0); put16(&o, 8 + 3 * nc); put8(&o, 8); put16(&o, (unsigned)h); put16(&o, (unsigned)w); put8(&o, nc);
     put8(&o, 1); put8(&o, (ssh << 4) | ssv); put8(&o, 0);
-    put8(&o, 2); put8(&o, 0x11); put8(&o, 1);
-    put8(&o, 3); put8(&o, 0x11); put8(&o, 1);
+    if (!gray) {
+        put8(&o, 2); put8(&o, 0x11); put8(&o, 1);
+        put8(&o, 3); put8(&o, 0x11); put8(&o, 1);
+    }
     put_dht(&o, 0x00, DC_L_BITS, DC_VALS); put_dht(&o, 0x10, AC_L_BITS, AC_L_VALS);
     put_dht(&o, 0x01, DC_C_BITS, DC_VALS); put_dht(&o, 0x11, AC_C_BITS, AC_C_VALS);
     if (restart_mcus > 0) { put16(&o, 0xFFDD); put16(&o, 4); put16(&o, (unsigned)restart_mcus); }
     /* SOS */
-    put16(&o, 0xFFDA); put16(&o, 6 + 6); put8(&o, 3);
-    put8(&o, 1); put8(&o, 0x00); put8(&o, 2); put8(&o, 0x11); put8(&o, 3); put8(&o, 0x11);
+    put16(&o, 0xFFDA); put16(&o, 6 + 2 * nc); put8(&o, nc);
+    put8(&o, 1); put8(&o, 0x00);
+    if (!gray) { put8(&o, 2); put8(&o, 0x11); put8(&o, 3); put8(&o, 0x11); }
     put8(&o, 0); put8(&o, 63); put8(&o, 0);
 
     enctab dcl, acl, dcc, acc_;
@@ -235,7 +239,7 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
                     fdct_quant(s, ql, qz);
                     encode_block(&o, qz, &pred[0], &dcl, &acl);
                 }
-            for (int c = 1; c < 3; ++c) {
+            for (int c = 1; c < nc; ++c) {
                 const float *P = c == 1 ? Cb : Cr;
                 for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
                     double a = 0;

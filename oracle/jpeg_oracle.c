@@ -414,6 +414,15 @@ static void store_unit(const ojpeg_info *info, uint8_t *img, const int M[8][8], 
 void ojpeg_pixels_from_qcoef(const ojpeg_info *info, const int32_t *qcoef, uint8_t *img) {
     unsigned mw = 8u * info->maxH, mh = 8u * info->maxV;
     size_t blk = 0;
+    /* Channels no scan component writes (grayscale: Cb, Cr).  The reference leaves them as the
+     * caller's malloc left them (src/test.c:28, src/decoding.c:107), i.e. undefined; this build
+     * defines them as 128, the neutral chroma, so that image_ycbcr_to_rgb yields gray. */
+    unsigned written = 0;
+    for (unsigned i = 0; i < info->ncomp; ++i)
+        if (info->scomp[i].id >= 1 && info->scomp[i].id <= 3) written |= 1u << (info->scomp[i].id - 1);
+    for (unsigned c = 0; c < 3; ++c)
+        if (!(written >> c & 1))
+            for (size_t p = 0; p < (size_t)info->width * info->height; ++p) img[3 * p + c] = 128;
     for (unsigned y = 0; y < info->height; y += mh)     /* src/jpeg.c:74 */
         for (unsigned x = 0; x < info->width; x += mw)  /* src/jpeg.c:75 */
             for (unsigned i = 0; i < info->ncomp; ++i) {

@@ -159,15 +159,17 @@ class Reference:
     def available():
         return os.path.exists(os.path.join(HERE, "_ref", "libjpegref.so"))
 
-    def decode(self, data, rgb=True):
-        """NOTE: on a stream the reference cannot decode it calls exit(1) (src/macros.h:8)."""
+    def decode(self, data, rgb=True, slack_rows=0):
+        """NOTE: on a stream the reference cannot decode it calls exit(1) (src/macros.h:8).
+        slack_rows: extra rows allocated behind the image -- on odd sizes with subsampling the
+        reference stores up to one row + one pixel past width*height (src/decoding.c:104-107)."""
         a = np.frombuffer(bytes(data), dtype=np.uint8)
         p = a.ctypes.data_as(C.POINTER(C.c_uint8))
         w, h = C.c_uint(), C.c_uint()
         rc = self.lib.refbench_decode(p, len(a), None, C.byref(w), C.byref(h), 0)
         if rc:
             return rc, None
-        out = np.zeros((h.value, w.value, 3), dtype=np.uint8)
+        out = np.zeros((h.value + slack_rows, w.value, 3), dtype=np.uint8)
         rc = self.lib.refbench_decode(p, len(a), out.ctypes.data_as(C.POINTER(C.c_uint8)),
                                       C.byref(w), C.byref(h), int(rgb))
-        return rc, out
+        return rc, out[:h.value]

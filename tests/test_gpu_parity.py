@@ -117,7 +117,7 @@ def test_seeded_synthetic_vs_oracle(pkg, dec, oracle, ss):
     files = []
     for i, (w, h) in enumerate(SHAPES):
         if (ss in (1, 2) and w % 2) or (ss in (1, 3) and h % 2):
-            continue  # odd sizes with subsampling are outside the reference's contract
+            continue  # odd sizes with subsampling: test_odd_sizes_with_subsampling_are_clipped
         q = int(rng.integers(20, 99))
         mcux = -(-w // (16 if ss in (1, 2) else 8))   # 0 = 4:4:4, 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:0
         for ri in (0, 1, mcux, 3 * mcux + 1):
@@ -125,6 +125,49 @@ def test_seeded_synthetic_vs_oracle(pkg, dec, oracle, ss):
     out = dec.decode(files)
     for i, f in enumerate(files):
         _check_against_oracle(pkg, oracle, out, i, f)
+
+
+@pytest.mark.parametrize("ss", [1, 2, 3])
+def test_odd_sizes_with_subsampling_are_clipped(pkg, dec, oracle, ss):
+    """odd widths / heights with shared chroma.  The reference replicates past the
+    image there (src/decoding.c:104-105); the oracle clips on the actual pixel and is pinned to
+    the reference wherever the reference's stores stay defined
+    (test_odd_sizes_with_subsampling_where_the_reference_is_defined)."""
+    files = []
+    for (w, h) in ((17, 17), (33, 21), (641, 481), (15, 1), (1, 15), (31, 32), (32, 31), (1, 1), (1919, 1079)):
+        mcux = -(-w // (16 if ss in (1, 2) else 8))
+        for ri in (0, mcux):
+            files.append(pkg.synth.make_jpeg(w, h, seed=w * h, quality=80, subsamp=ss, restart_mcus=ri))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    planar = dec.decode(files, pkg.OUT_PLANAR)
+    for i in (0, 5, len(files) - 1):
+        assert np.array_equal(planar.pixels(i), out.pixels(i).transpose(2, 0, 1))
+
+
+def test_grayscale_streams(pkg, dec, oracle):
+    """one-component streams next to colour ones in one batch, with and without
+    restart markers; coefficients and pixels equal the oracle's (absent channels = 128), every
+    output layout"""
+    files = []
+    for (w, h, q, ri) in ((64, 48, 80, 0), (37, 21, 30, 0), (200, 136, 95, 5), (1, 1, 50, 0),
+                          (640, 480, 85, 80), (1920, 1080, 85, 0)):
+        files.append(pkg.synth.make_jpeg(w, h, seed=w + h, quality=q, subsamp=4, restart_mcus=ri))
+        files.append(pkg.synth.make_jpeg(w + (w & 1), h + (h & 1), seed=w + h, quality=q, subsamp=1, restart_mcus=ri))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    g = out.pixels(0)
+    assert np.array_equal(g[..., 0], g[..., 1]) and np.array_equal(g[..., 1], g[..., 2])
+    ycc = dec.decode(files, pkg.OUT_YCBCR | pkg.OUT_PLANAR)
+    for i in range(0, len(files), 2):
+        rc, want = oracle.ycbcr(files[i])
+        assert rc == 0 and np.array_equal(ycc.pixels(i), want.transpose(2, 0, 1))
+    # two components, or one with sampling factors other than 1x1: reported, not decoded
+    d = pkg.parse(files[0])
+    d.comp[0].H = 2
+    assert pkg.Batch([d]).decode().status(0) == pkg.IMG_UNSUPPORTED
 
 
 def test_noise_images_long_codes(pkg, dec, oracle):

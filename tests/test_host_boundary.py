@@ -130,6 +130,38 @@ def test_threaded_parse_equals_single(pkg, threads):
     assert len(pkg.parse_many([], threads=threads)) == 0
 
 
+def test_table_redefinitions_last_one_wins(pkg, oracle):
+    """a DQT / DHT id defined twice before the scan.  The reference rebuilds the tree
+    (src/hufftree.c:44 memsets the root, leaking the old children) and overwrites the quantisation
+    table, so the last definition is the one in force; here: descriptor identical to the stream
+    without the extra segments, and the unmodified reference decodes both to the same pixels."""
+    from oracle.oracle import Reference
+    good = golden_stream("syn_64x48_420_q85")
+    q = good.index(b"\xff\xdb")
+    qlen = int.from_bytes(good[q + 2:q + 4], "big")
+    dqt = bytearray(good[q:q + 2 + qlen])
+    for k in range(5, 5 + 64):
+        dqt[k] = 255 - dqt[k] % 200            # another luma table, same id
+    h = good.index(b"\xff\xc4")
+    # the second DHT segment (AC luma, 0x10) re-labelled as DC luma (0x00) and put in front
+    h2 = good.index(b"\xff\xc4", h + 2)
+    h2len = int.from_bytes(good[h2 + 2:h2 + 4], "big")
+    dht = bytearray(good[h2:h2 + 2 + h2len])
+    assert dht[4] == 0x10
+    dht[4] = 0x00
+    twice = good[:q] + bytes(dqt) + good[q:h] + bytes(dht) + good[h:]
+    a, b = pkg.parse(good), pkg.parse(twice)
+    size = C.sizeof(pkg.ImageDesc)
+    assert C.string_at(C.addressof(a), size)[8:] == C.string_at(C.addressof(b), size)[8:]
+    assert oracle.parse(twice)[0] == 0
+    rc1, rgb1 = oracle.rgb(good)
+    rc2, rgb2 = oracle.rgb(twice)
+    assert rc1 == 0 and rc2 == 0 and np.array_equal(rgb1, rgb2)
+    if Reference.available():
+        ref = Reference()
+        assert np.array_equal(ref.decode(twice)[1], ref.decode(good)[1])
+
+
 def _canonical_decode(counts, symbols, v16):
     """bit-by-bit canonical walk (the tree of src/hufftree.c:46-59 as first/count per length)"""
     code, first, k = 0, 0, 0
