@@ -170,6 +170,9 @@ long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t
 
 /* ---- image.h on the device: src/image.c:39-51 over a host buffer (H2D, kernel, D2H) ------ */
 int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height);
+/* src/image.c:54-66 the same way (row f4 of SURVEY 8; off the decode path: image_rgb_to_ycbcr of
+ * include/image.h stays host C, this is for callers whose pixels are large) */
+int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
-    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_rgb_to_ycbcr",
     "jdgpu_host_lut_lookup", "jdgpu_host_unstuff", "jdgpu_batch_debug_segments",
     "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
@@ -110,6 +110,7 @@ def lib():
     L.jdgpu_batch_retries.argtypes = [vp]
     L.jdgpu_batch_repair_counts.argtypes = [vp, C.POINTER(C.c_uint32), sz]
     L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
+    L.jdgpu_rgb_to_ycbcr.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_host_lut_lookup.argtypes = [C.POINTER(HuffSpec), C.c_int, C.c_uint, C.POINTER(C.c_uint),
                                         C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
@@ -351,6 +352,17 @@ def ycbcr_to_rgb(img):
     rc = L.jdgpu_ycbcr_to_rgb(out.ctypes.data, w, h)
     if rc:
         raise _err(L, "jdgpu_ycbcr_to_rgb", rc)
+    return out
+
+
+def rgb_to_ycbcr(img):
+    """image_rgb_to_ycbcr (src/image.c:54-66) on the GPU over an (h, w, 3) uint8 array."""
+    L = lib()
+    out = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    h, w = out.shape[:2]
+    rc = L.jdgpu_rgb_to_ycbcr(out.ctypes.data, w, h)
+    if rc:
+        raise _err(L, "jdgpu_rgb_to_ycbcr", rc)
     return out
 
 

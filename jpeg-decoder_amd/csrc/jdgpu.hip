@@ -996,17 +996,21 @@ __device__ __forceinline__ uint32_t to_sample(double v) {
  *   G = clamp(Y + floor(-(34414 cb + 71414 cr) / 100000))
  * The real-valued sums are at least 1e-5 away from an integer unless they ARE integers, so the
  * reference's double evaluation and the exact rational floor agree -- except for the one
- * (cb, cr) pair noted below.  The floors are taken in f32 on values shifted positive, with
- * proven margins (R, B: fractions are multiples of 0.002, f32 error < 4e-5; G: the quotient
- * (n/32 + 0.5) / 3125 keeps fractions inside [1.5e-4, 1 - 1.5e-4], f32 error < 5e-5).  The whole
+ * (cb, cr) pair noted below.  R, B: multiply-shift floors (below); G: the floor is taken in f32
+ * on a value shifted positive, with a proven margin (the quotient (n/32 + 0.5) / 3125 keeps
+ * fractions inside [1.5e-4, 1 - 1.5e-4], f32 error < 5e-5).  The whole
  * function is checked over all 2^24 (Y, Cb, Cr) against the oracle (tests/test_gpu_parity.py).
  */
 struct ChromaTerms { int dr, dg, db; uint32_t exc; };
 __device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
     int cb = cbv - 128, cr = crv - 128;
     ChromaTerms t;
-    t.dr = (int)fmaf(1.402f, (float)cr, 256.0f) - 256;
-    t.db = (int)fmaf(1.772f, (float)cb, 256.0f) - 256;
+    /* floor(1.402 c) = (c * 91882) >> 16 and floor(1.772 c) = (c * 116130) >> 16 for every c in
+     * -128..127: the multipliers exceed 1.402 * 2^16 and 1.772 * 2^16 by < 0.6, i.e. the product
+     * is off by < 0.0012, while the fractions of 1.402 c and 1.772 c are multiples of 0.002 and
+     * 0.004 (zero only at c = 0) */
+    t.dr = __mul24(cr, 91882) >> 16;
+    t.db = __mul24(cb, 116130) >> 16;
     /* floor(n / 100000) = floor(floor(n / 32) / 3125), n = 25600000 - (34414 cb + 71414 cr) > 0 */
     uint32_t m = (uint32_t)(25600000 - __mul24(34414, cb) - __mul24(71414, cr)) >> 5;
     const float inv = 1.0f / 3125.0f;
@@ -1042,16 +1046,25 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
             ct[3] = ct[2];
         }
     }
-    /* wave-uniform: almost no wave ever meets the exceptional chroma pair */
-    const bool any_exc = !OUT_YCBCR && __any((int)(ct[0].exc | ct[1].exc | ct[2].exc | ct[3].exc));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int Y = (int)((y4 >> (8 * i)) & 255u);
         if (OUT_YCBCR) { r.o[3 * i] = (uint32_t)Y; r.o[3 * i + 1] = cbv[i]; r.o[3 * i + 2] = crv[i]; }
         else {
             r.o[3 * i] = clamp255(Y + ct[i].dr);
-            r.o[3 * i + 1] = clamp255(Y + ct[i].dg - (any_exc ? green_fix(ct[i], Y) : 0));
+            r.o[3 * i + 1] = clamp255(Y + ct[i].dg);
             r.o[3 * i + 2] = clamp255(Y + ct[i].db);
+        }
+    }
+    /* wave-uniform and almost never taken: a lane of the wave holds the exceptional chroma pair.
+     * Kept a real branch (the empty asm stops the compiler from turning it into selects, which
+     * cost every wave 16 instructions per row). */
+    if (!OUT_YCBCR && __any((int)(ct[0].exc | ct[1].exc | ct[2].exc | ct[3].exc))) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int Y = (int)((y4 >> (8 * i)) & 255u);
+            r.o[3 * i + 1] = clamp255(Y + ct[i].dg - green_fix(ct[i], Y));
         }
     }
     return r;
@@ -1311,6 +1324,19 @@ __global__ void k_ycbcr_to_rgb(uint8_t *px, size_t npix) {
     px[3 * i] = (uint8_t)clamp255(Y + ct.dr);
     px[3 * i + 1] = (uint8_t)clamp255(Y + ct.dg - green_fix(ct, Y));
     px[3 * i + 2] = (uint8_t)clamp255(Y + ct.db);
+}
+
+/* image_rgb_to_ycbcr on a device buffer: src/image.c:54-66 literally -- the same f64 products and
+ * sums in the same order (the build disables contraction), clamp, truncating store.  The forward
+ * transform has no integer shortcut worth proving: it is off the decode path. */
+__device__ __forceinline__ uint8_t clamp_trunc(double v) { return (uint8_t)(v < 0 ? 0.0 : 255 < v ? 255.0 : v); }
+__global__ void k_rgb_to_ycbcr(uint8_t *px, size_t npix) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const double R = px[3 * i], G = px[3 * i + 1], B = px[3 * i + 2];
+    px[3 * i] = clamp_trunc(0.299 * R + 0.587 * G + 0.114 * B);
+    px[3 * i + 1] = clamp_trunc(-0.1687 * R - 0.3313 * G + 0.5 * B + 128.0);
+    px[3 * i + 2] = clamp_trunc(0.5 * R - 0.4187 * G - 0.0813 * B + 128.0);
 }
 
 /* ============================================================================================
@@ -1710,20 +1736,31 @@ extern "C" int jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]) {
     return JDGPU_OK;
 }
 
-extern "C" int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height) {
+/* in-place conversion of a host pixel[] buffer on the device: upload, kernel, download */
+static int convert_host_pixels(void (*kernel)(uint8_t *, size_t), const char *what, void *host_pixels,
+                               unsigned width, unsigned height) {
     int rc = ensure_device();
     if (rc) return rc;
     size_t npix = (size_t)width * height;
     if (!npix) return JDGPU_OK;
+    if (!host_pixels) { snprintf(g_err, sizeof g_err, "%s: null buffer", what); return JDGPU_ERR_ARG; }
     uint8_t *d = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), npix * 3));
     hipError_t e = hipMemcpy(d, host_pixels, npix * 3, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_ycbcr_to_rgb, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, d, npix);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, d, npix);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost);
     hipFree(d);
-    if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "jdgpu_ycbcr_to_rgb: %s", hipGetErrorString(e)); return JDGPU_ERR_HIP; }
+    if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e)); return JDGPU_ERR_HIP; }
     return JDGPU_OK;
+}
+
+extern "C" int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height) {
+    return convert_host_pixels(k_ycbcr_to_rgb, "jdgpu_ycbcr_to_rgb", host_pixels, width, height);
+}
+
+extern "C" int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height) {
+    return convert_host_pixels(k_rgb_to_ycbcr, "jdgpu_rgb_to_ycbcr", host_pixels, width, height);
 }

@@ -97,6 +97,82 @@ def test_exhaustive_colour(pkg, dec, oracle):
     assert np.array_equal(pkg.ycbcr_to_rgb(img), oracle.to_rgb(img))
 
 
+def _flat_block_jpeg(pkg, oracle, mcus, w, h):
+    """a 4:4:4 stream with quantisation tables of ones whose 8x8 units are flat: `mcus` lists one
+    (Y, Cb, Cr) sample triple per MCU (raster order).  Lets a test put ANY YCbCr triple in front
+    of the colour stage, including ones no RGB image encodes to."""
+    base = pkg.synth.make_jpeg(w, h, seed=1, quality=100, subsamp=0)
+    d = pkg.parse(base)
+    assert all(v == 1 for t in (0, 1) for v in d.quant[t])
+    hdr = base[:len(base) - d.scan_len]
+
+    def codes(spec):
+        out, code, k = {}, 0, 0
+        for ln in range(1, 17):
+            for _ in range(spec.counts[ln - 1]):
+                out[spec.symbols[k]] = (code, ln)
+                code += 1
+                k += 1
+            code <<= 1
+        return out
+    dc = [codes(d.huff[0][0]), codes(d.huff[0][1]), codes(d.huff[0][1])]
+    eob = [codes(d.huff[1][0])[0], codes(d.huff[1][1])[0], codes(d.huff[1][1])[0]]
+    acc, nbits, pred = 0, 0, [0, 0, 0]
+    for triple in mcus:
+        for c, v in enumerate(triple):
+            coef = (int(v) - 128) * 8            # flat unit: sample = DC / 8 + 128 (T[0][x]^2 / 4 = 1/8)
+            diff, pred[c] = coef - pred[c], coef
+            cat = abs(diff).bit_length()
+            code, ln = dc[c][cat]
+            acc, nbits = (acc << ln) | code, nbits + ln
+            if cat:
+                acc, nbits = (acc << cat) | (diff if diff > 0 else diff + (1 << cat) - 1), nbits + cat
+            code, ln = eob[c]
+            acc, nbits = (acc << ln) | code, nbits + ln
+    pad = -nbits % 8
+    acc, nbits = (acc << pad) | ((1 << pad) - 1), nbits + pad
+    scan = acc.to_bytes(nbits // 8, "big").replace(b"\xff", b"\xff\x00")
+    return hdr + scan + b"\xff\xd9"
+
+
+def test_exceptional_chroma_pair_through_the_pixel_kernel(pkg, dec, oracle):
+    """(Cb, Cr) = (28, 228) with Y in 94..165 is the one input where the reference's doubles land
+    below the exact value (src/image.c:46) and G comes out one less; the fused colour stage of
+    k_pixel takes a separate, wave-uniform branch for it.  Flat units put the pair (and its
+    neighbours, and Y on both sides of the range) in front of that stage."""
+    triples = []
+    for y in (0, 93, 94, 95, 128, 164, 165, 166, 255):
+        for cb, cr in ((28, 228), (27, 228), (28, 227), (29, 228), (28, 229), (128, 128)):
+            triples.append((y, cb, cr))
+    w, h = 8 * 9, 8 * 6
+    assert len(triples) == (w // 8) * (h // 8)
+    f = _flat_block_jpeg(pkg, oracle, triples, w, h)
+    rc, ycc = oracle.ycbcr(f)
+    assert rc == 0
+    for k, t in enumerate(triples):   # the stream holds what was asked for
+        assert tuple(ycc[(k // 9) * 8 + 3, (k % 9) * 8 + 5]) == t
+    want = oracle.to_rgb(ycc)
+    k = triples.index((128, 28, 228))
+    assert want[(k // 9) * 8, (k % 9) * 8, 1] == 128 - 38   # exact arithmetic says 128 - 37
+    for flags, view in ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0))):
+        out = dec.decode([f, golden_stream("syn_200x136_444_q95"), f], flags)
+        assert out.status(0) == 0
+        assert np.array_equal(view(out.pixels(0)), want)
+        assert np.array_equal(view(out.pixels(2)), want)
+    # 4:2:0 instantiation: the same chroma under 2x2 luma units
+    base = pkg.synth.make_jpeg(16, 16, seed=1, quality=100, subsamp=1)
+    out = dec.decode([base])
+    _check_against_oracle(pkg, oracle, out, 0, base)
+
+
+def test_exhaustive_forward_colour(pkg, dec, oracle):
+    """jdgpu_rgb_to_ycbcr over all 2^24 (R,G,B) == src/image.c:54-66 (oracle, itself pinned to the
+    reference over the same 2^24 inputs in tests/test_oracle_golden.py)"""
+    r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    img = np.stack([r, g, b], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(pkg.rgb_to_ycbcr(img), oracle.to_ycbcr(img))
+
+
 def test_cli_reproduces_reference_stdout(manifest):
     """config 1 of BASELINE.json: the demo viewer on birb.jpg, byte-identical terminal dump"""
     exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
