@@ -1076,21 +1076,19 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
 #define JD_FMT_4 1u       /* 4 interleaved bytes, the fourth 255 */
 #define JD_FMT_PLANAR 2u  /* three planes of width*height bytes */
 template <uint32_t FMT>
-__device__ __forceinline__ void store_px4(uint8_t *out, uint32_t W, uint32_t H, uint32_t x, uint32_t y,
-                                          const Px4 &v, bool aligned, uint32_t npx) {
-    const uint32_t *o = v.o;
-    const size_t at = (size_t)y * W + x;
+__device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t at, const Px4 &v, bool aligned,
+                                          uint32_t npx) {
+    const uint32_t *o = v.o; /* at = y * width + x (< 2^32: both are 16-bit), plane = width * height */
     if (FMT == JD_FMT_4) {
         /* 16 bytes per lane, always aligned (x is a multiple of 4, images start on 256 bytes) */
         uint32_t p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[i] = o[3 * i] | (o[3 * i + 1] << 8) | (o[3 * i + 2] << 16) | 0xFF000000u;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out + at * 4);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 4);
         if (npx == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
         else
             for (uint32_t i = 0; i < npx; ++i) dst[i] = p[i];
     } else if (FMT == JD_FMT_PLANAR) {
-        const size_t plane = (size_t)W * H;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t w = o[c] | (o[3 + c] << 8) | (o[6 + c] << 16) | (o[9 + c] << 24);
@@ -1104,10 +1102,10 @@ __device__ __forceinline__ void store_px4(uint8_t *out, uint32_t W, uint32_t H, 
                                o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24),
                                o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24)};
         if (aligned) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(out + at * 3);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 3);
             dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
         } else {
-            for (uint32_t i = 0; i < npx * 3; ++i) out[at * 3 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+            for (uint32_t i = 0; i < npx * 3; ++i) out[(size_t)at * 3 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
     }
 }
@@ -1194,6 +1192,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const bool draws = x < W && 4u * g < my_mcus * 8u * maxH;   /* lane has pixels in phase 2 */
     const uint32_t npx = draws ? min(4u, W - x) : 0u;
     const uint8_t *tY = tile, *tB = tile + PLANE1, *tR = tile + PLANE2;
+    const size_t plane = (size_t)W * H;
 
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
@@ -1258,32 +1257,36 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         const uint32_t y0 = mrow * 8u * maxV;
         const uint32_t rows = min(8u * maxV, H - y0);
         if (draws) {
+            /* 24-bit multiplies for the row offsets and the pixel index (rows, widths < 2^16): a
+             * full 32-bit or 64-bit multiply costs as much as four plain instructions */
             if (MODE == JD_PIX_420) {
                 /* lane: 4 pixels x 2 rows sharing one chroma row */
-                for (uint32_t rp = rq; 2u * rp < rows; rp += 4) {
-                    uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[rp * PIX_ROW + 2u * g]);
-                    uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[rp * PIX_ROW + 2u * g]);
+                uint32_t offC = rq * PIX_ROW + 2u * g; /* carried: the compiler makes rp * 72 a full multiply */
+                for (uint32_t rp = rq; 2u * rp < rows; rp += 4, offC += 4u * PIX_ROW) {
+                    uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[offC]);
+                    uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[offC]);
                     const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
                     const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
 #pragma unroll
                     for (uint32_t dy = 0; dy < 2; ++dy) {
                         uint32_t r = 2u * rp + dy;
                         if (r < rows) {
-                            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
+                            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[2u * offC + dy * PIX_ROW]);
                             Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
-                            store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
+                            store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
                         }
                     }
                 }
             } else if (MODE == JD_PIX_444) {
-                for (uint32_t r = rq; r < rows; r += 4) {
-                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[r * PIX_ROW + 4u * g]);
-                    uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[r * PIX_ROW + 4u * g]);
-                    uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[r * PIX_ROW + 4u * g]);
+                uint32_t off = rq * PIX_ROW + 4u * g;
+                for (uint32_t r = rq; r < rows; r += 4, off += 4u * PIX_ROW) {
+                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[off]);
+                    uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[off]);
+                    uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[off]);
                     const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
                     const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
                     Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
-                    store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
+                    store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
                 }
             } else {
                 /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
@@ -1307,7 +1310,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     }
                     uint32_t y4 = sm[0][0] | (sm[0][1] << 8) | (sm[0][2] << 16) | (sm[0][3] << 24);
                     Px4 v = colour4<OUT_YCBCR>(y4, sm[1], sm[2], 4);
-                    store_px4<FMT>(out, W, H, x, y0 + r, v, aligned, npx);
+                    store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
                 }
             }
         }
