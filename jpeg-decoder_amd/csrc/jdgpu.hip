@@ -736,12 +736,14 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
                                                   const uint32_t *__restrict__ seg_info,
                                                   const int4 *__restrict__ cnt,
                                                   int2 *__restrict__ start_blk,
-                                                  int4 *__restrict__ start_dc) {
+                                                  int4 *__restrict__ start_dc,
+                                                  uint32_t *__restrict__ status) {
     __shared__ ScanVal s_wave[4];
     __shared__ ScanVal s_carry;
     const jd_image &im = imgs[blockIdx.x];
     const uint32_t n_segs = im.n_segs, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_carry.n = s_carry.d0 = s_carry.d1 = s_carry.d2 = 0; s_carry.f = 0; }
+    if (threadIdx.x == 0 && im.ncomp && n_segs == 0) atomicOr(&status[blockIdx.x], (uint32_t)JDGPU_IMG_EOF);
     __syncthreads();
     for (uint32_t base = 0; base < n_segs; base += 256) {
         uint32_t seg = base + threadIdx.x;
@@ -778,6 +780,10 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
             else { b0 = ibase + inc.n - own.n; p0 = inc.d0 - own.d0; p1 = inc.d1 - own.d1; p2 = inc.d2 - own.d2; }
             start_blk[im.seg_off + seg] = make_int2(b0, limit);
             start_dc[im.seg_off + seg] = make_int4(p0, p1, p2, 0);
+            /* fewer restart markers in the stream than the geometry needs: the trailing
+             * intervals have no segment and so no lane that could notice; their data units
+             * are missing -- "Reached end of file." (src/bitstream.c:17) */
+            if (seg + 1 == n_segs && inc.f < im.n_intervals) atomicOr(&status[blockIdx.x], (uint32_t)JDGPU_IMG_EOF);
         }
         __syncthreads();
     }
@@ -1606,7 +1612,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
     if (P.n_hwg) { if (int rc = enqueue_huffman(b, true)) return rc; }
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
-    hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
+    hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
     if (P.n_hwg)
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
@@ -1649,7 +1655,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
             for (size_t i = 0; i < P.n; ++i) clean &= lc[i] == 0;
             if (clean) break;
         }
-        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
         hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
                            b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
         launch_pixel(b, s);

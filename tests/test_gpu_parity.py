@@ -435,6 +435,24 @@ def test_torch_views_alias_the_output(pkg, dec):
     assert np.array_equal(ragged.tensor(1).cpu().numpy(), ragged.pixels(1))
 
 
+def test_missing_restart_markers_are_eof(pkg, dec, oracle):
+    """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
+    intervals never start, their data units are missing -> "Reached end of file." like the
+    oracle, in every mix with intact streams; plus one built here with the marker bytes cut out"""
+    bad_dir = os.path.join(ROOT, "tests", "golden", "streams_bad")
+    bad = [open(os.path.join(bad_dir, n), "rb").read() for n in sorted(os.listdir(bad_dir))]
+    good = pkg.synth.make_jpeg(96, 64, seed=3, quality=80, subsamp=1, restart_mcus=2)
+    i = good.index(b"\xff\xd3")
+    cut = good[:i] + good[i + 2:]          # RST3 removed: one interval short
+    files = [good] + bad + [cut, good]
+    out = dec.decode(files)
+    assert out.status(0) == 0 and out.status(len(files) - 1) == 0
+    for k in range(1, len(files) - 1):
+        rc = oracle.qcoef(files[k])[0]
+        assert rc == -2
+        assert out.status(k) & pkg.IMG_EOF, (k, out.status(k))
+
+
 def test_unsupported_layout_is_reported_not_decoded(pkg, dec):
     d = pkg.parse(golden_stream("syn_8x8_444_q85"))
     d.comp[0].id = 7   # channel = id-1 would be out of range (src/decoding.c:107)

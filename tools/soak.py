@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Development aid: randomized parity soak on the GPU box.  N random streams (sizes 1..400, all five
+layouts, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
+decoded in batches of 256 in every output layout, each compared with the oracle: status class,
+coefficients and pixels bit for bit.  usage: soak.py [N] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from oracle.oracle import Oracle
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+oracle = Oracle()
+dec = pkg.Decoder(0)
+want_bits = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}
+LAYOUTS = ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_4BYTE, lambda a: a[..., :3]), (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0)))
+bad = done = failed_streams = 0
+t0 = time.time()
+while done < N:
+    files = []
+    for _ in range(min(256, N - done)):
+        ss = int(rng.integers(0, 5))
+        w, h = int(rng.integers(1, 401)), int(rng.integers(1, 401))
+        q = int(rng.integers(1, 101))
+        mcus = -(-w // (16 if ss in (1, 2) else 8)) * -(-h // (16 if ss in (1, 3) else 8))
+        ri = 0 if rng.random() < 0.5 else int(rng.integers(1, mcus + 2))
+        kind = rng.random()
+        if kind < 0.7:
+            f = pkg.synth.make_jpeg(w, h, seed=int(rng.integers(1 << 30)), quality=q, subsamp=ss, restart_mcus=ri)
+        elif kind < 0.85:
+            f = pkg.synth.encode_rgb(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), quality=q, subsamp=ss, restart_mcus=ri)
+        else:
+            f = pkg.synth.encode_rgb(np.full((h, w, 3), int(rng.integers(256)), np.uint8), quality=q, subsamp=ss, restart_mcus=ri)
+        if rng.random() < 0.15:   # corrupt the scan
+            g = bytearray(f)
+            off = oracle.parse(f)[1].scan_offset
+            pos = off + int(rng.integers(0, max(1, len(g) - off - 2)))
+            c = rng.random()
+            if c < 0.4: g[pos] ^= 1 << int(rng.integers(8))
+            elif c < 0.7: g = g[:pos]
+            else: g[pos:pos + 2] = bytes([0xFF, int(rng.integers(256))])
+            f = bytes(g)
+        files.append(f)
+    flags, view = LAYOUTS[(done // 256) % 3]
+    out = dec.decode(files, flags)
+    for i, f in enumerate(files):
+        rc, info, qc = oracle.qcoef(f)
+        if rc:
+            failed_streams += 1
+            ok = bool(out.status(i) & want_bits[rc])
+        else:
+            ok = out.status(i) == 0 and np.array_equal(out.qcoef(i).astype(np.int32), qc) and \
+                np.array_equal(view(out.pixels(i)), oracle.to_rgb(oracle.pixels_from_qcoef(info, qc)))
+        if not ok:
+            bad += 1
+            d = pkg.parse(f)
+            print(f"MISMATCH stream {done + i}: {d.width}x{d.height} ncomp {d.ncomp} H{d.comp[0].H}V{d.comp[0].V} ri {d.restart_interval} "
+                  f"len {len(f)} oracle rc {rc} status {out.status(i)}", flush=True)
+            os.makedirs("gpurun_out/soak_bad", exist_ok=True)
+            open(f"gpurun_out/soak_bad/s{seed}_{done + i}.jpg", "wb").write(f)
+    done += len(files)
+    print(f"{done} streams, {failed_streams} undecodable by design, {bad} mismatches, retries {out.retries}, {time.time() - t0:.0f} s", flush=True)
+    out.close()
+sys.exit(1 if bad else 0)
