@@ -2,7 +2,7 @@
 """Development aid: randomized parity soak on the GPU box.  N random streams (sizes 1..400, all five
 layouts, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
 decoded in batches of 256 in every output layout, each compared with the oracle: status class,
-coefficients and pixels bit for bit.  usage: soak.py [N] [seed]"""
+coefficients and pixels bit for bit.  usage: soak.py [N] [seed] [max_side, default 400]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,8 @@ from oracle.oracle import Oracle
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+SIDE = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+CHUNK = 256 if SIDE <= 400 else 32
 rng = np.random.default_rng(seed)
 oracle = Oracle()
 dec = pkg.Decoder(0)
@@ -21,9 +23,9 @@ bad = done = failed_streams = 0
 t0 = time.time()
 while done < N:
     files = []
-    for _ in range(min(256, N - done)):
+    for _ in range(min(CHUNK, N - done)):
         ss = int(rng.integers(0, 5))
-        w, h = int(rng.integers(1, 401)), int(rng.integers(1, 401))
+        w, h = int(rng.integers(1, SIDE + 1)), int(rng.integers(1, SIDE + 1))
         q = int(rng.integers(1, 101))
         mcus = -(-w // (16 if ss in (1, 2) else 8)) * -(-h // (16 if ss in (1, 3) else 8))
         ri = 0 if rng.random() < 0.5 else int(rng.integers(1, mcus + 2))
@@ -44,7 +46,7 @@ while done < N:
             else: g[pos:pos + 2] = bytes([0xFF, int(rng.integers(256))])
             f = bytes(g)
         files.append(f)
-    flags, view = LAYOUTS[(done // 256) % 3]
+    flags, view = LAYOUTS[(done // CHUNK) % 3]
     out = dec.decode(files, flags)
     for i, f in enumerate(files):
         rc, info, qc = oracle.qcoef(f)
