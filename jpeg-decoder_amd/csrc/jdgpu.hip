@@ -1178,8 +1178,11 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 
     /* ---- phase 1 ---- */
     const uint32_t l = lane & 7u, slot = lane >> 3;
-    /* transpose buffer: element (y, u) of slot s at s*64 + y*8 + (((u + y) & 7) ^ (s & 3)):
-     * the 32 lanes of a half-wave that read (their y, step u) hit 32 different bank pairs */
+    /* transpose buffer: element (y, u) of slot s at s*64 + (y ^ (s & 3))*8 + ((u + y) & 7).
+     * ds_write_b64 is served 16 lanes at a time over 32 dword banks, ds_read_b64 32 lanes over 64:
+     * the 16 lanes (2 slots) that write step y hit 16 different bank pairs and the 32 lanes
+     * (4 slots) that read step u hit 32 (searched exhaustively; the earlier swizzle
+     * (u + y) ^ (s & 3) in the column made every write 2-way: 36 % of the kernel's LDS cycles) */
     double *tr = s_tr + (wave * 8u + slot) * TR_BLK;
     uint8_t *tile = s_tile[wave];
     const uint32_t sx = slot & 3u;
@@ -1238,12 +1241,12 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     }
                     idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
 #pragma unroll
-                    for (int y = 0; y < 8; ++y) tr[y * 8 + (((l + y) & 7u) ^ sx)] = t[y];
+                    for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
                 }
                 WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
                 if (act) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) col[u] = tr[l * 8 + (((u + l) & 7u) ^ sx)];
+                    for (int u = 0; u < 8; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
                     idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
                     uint32_t w0 = 0, w1 = 0;
 #pragma unroll
@@ -1267,8 +1270,13 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
              * full 32-bit or 64-bit multiply costs as much as four plain instructions */
             if (MODE == JD_PIX_420) {
                 /* lane: 4 pixels x 2 rows sharing one chroma row */
-                uint32_t offC = rq * PIX_ROW + 2u * g; /* carried: the compiler makes rp * 72 a full multiply */
-                for (uint32_t rp = rq; 2u * rp < rows; rp += 4, offC += 4u * PIX_ROW) {
+                /* chroma rows of lane group rq: {0,2}, {4,6}, {1,3}, {5,7} -- the two groups that
+                 * share a 32-lane LDS access read luma rows 8 apart (16 banks apart: no conflict;
+                 * 2 apart would overlap on 12 of 16 banks).  offC is carried: the compiler makes
+                 * rp * 72 a full multiply */
+                const uint32_t rp0 = (rq & 1u) * 4u + (rq >> 1);
+                uint32_t offC = rp0 * PIX_ROW + 2u * g;
+                for (uint32_t rp = rp0; rp < rp0 + 4u && 2u * rp < rows; rp += 2, offC += 2u * PIX_ROW) {
                     uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[offC]);
                     uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[offC]);
                     const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
