@@ -621,13 +621,17 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
 
-    const jd_huff_wg wg = wgs[blockIdx.x];
+    /* one descriptor per wave; the waves of a work-group may serve different images, whose
+     * tables and unit layout the plan made sure are the same (staged from the first wave's) */
+    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)];
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
-    if (wg.seg0 >= n_segs) return;
-    const uint32_t seg = wg.seg0 + threadIdx.x;
-    stage_tables(s_lut, s_blk, luts + im.lut_off, im, 1);
+    if (!__syncthreads_or(wg.seg0 < n_segs)) return; /* seg_cap is an upper bound: trailing groups are empty */
+    const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
+    stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, 1);
     __syncthreads();
+    if (wg.seg0 >= n_segs) return;
+    const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
     if (seg >= n_segs) return;
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
     const uint8_t *const cimg = clean + im.clean_off;
@@ -653,11 +657,11 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__re
                                                             const uint32_t *__restrict__ st_exit,
                                                             uint32_t *__restrict__ list,
                                                             uint32_t *__restrict__ list_cnt) {
-    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)];
     const jd_image &im = imgs[wg.img];
-    const uint32_t seg = wg.seg0 + threadIdx.x;
+    const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
     bool broken = false;
-    if (seg < im.n_segs) {
+    if (wg.seg0 < im.n_segs && seg < im.n_segs) {
         const uint32_t gs = im.seg_off + seg;
         const uint32_t want = (seg_info[gs] & JD_SEG_FIRST) ? 0u : (st_exit[gs - 1] & ~JD_ST_BAD);
         broken = st_in[gs] != want;
@@ -687,13 +691,15 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
 
-    const jd_huff_wg wg = wgs[blockIdx.x];   /* here: entries [seg0, seg0 + JD_WG_SEGS) of the image's list */
+    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)]; /* here: entries [seg0, seg0 + 64) of the image's list */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_list = min(list_cnt[wg.img], im.n_segs);
-    if (wg.seg0 >= n_list) return;
-    stage_tables(s_lut, s_blk, luts + im.lut_off, im, 1);
+    if (!__syncthreads_or(wg.seg0 < n_list)) return; /* the usual case from the second round on */
+    const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
+    stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, 1);
     __syncthreads();
-    const uint32_t idx = wg.seg0 + threadIdx.x;
+    if (wg.seg0 >= n_list) return;
+    const uint32_t idx = wg.seg0 + (threadIdx.x & 63u);
     if (idx >= n_list) return;
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
     const uint32_t seg = list[im.seg_off + idx];
@@ -830,14 +836,17 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
     __shared__ uint8_t s_cm[64];
 
-    const jd_huff_wg wg = wgs[blockIdx.x];
+    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)]; /* per wave, see k_huff_first */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
-    if (wg.seg0 >= n_segs) return;
-    const uint32_t lane = threadIdx.x, seg = wg.seg0 + lane;
-    const uint32_t wlane = lane & 63u, wbase = lane & ~63u;
+    if (!__syncthreads_or(wg.seg0 < n_segs)) return;
+    const uint32_t lane = threadIdx.x, wlane = lane & 63u, wbase = lane & ~63u;
+    const uint32_t seg = wg.seg0 + wlane;
     const jd_lut *const g_lut = luts + im.lut_off;
-    stage_tables(s_lut, s_blk, g_lut, im, -1);
+    {
+        const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
+        stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, -1);
+    }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
         uint4 *z = reinterpret_cast<uint4 *>(s_buf + lane * WBUF_BYTES);
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
         for (int q = 0; q < 8; ++q) z[q] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    bool active = seg < n_segs;
+    bool active = wg.seg0 < n_segs && seg < n_segs;
     if (!__any(active)) return; /* whole wave beyond the image: no further work-group barrier below */
 
     const uint32_t gs = im.seg_off + (active ? seg : wg.seg0);
@@ -1511,10 +1520,10 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_list_cnt, (size_t)JD_REPAIR_ROUNDS * (n ? n : 1)));
     TRY(dalloc(&b->d_status, n));
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
-    TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg));
+    TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
     TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
-    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg));
+    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_chunk_cnt, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_chunk_base, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_ivl_u, (size_t)P.n_u));
@@ -1538,10 +1547,10 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     }
     HIPTRY(hipMemcpy(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     if (trace) { HIPTRY(hipDeviceSynchronize()); fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
     HIPTRY(hipMemset(b->d_pix, 0, (size_t)P.pix_bytes + 256));
     HIPTRY(hipMemset(b->d_status, 0, (n ? n : 1) * 4));

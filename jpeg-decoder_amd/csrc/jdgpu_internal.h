@@ -148,7 +148,10 @@ typedef struct {
 } jd_image; /* keep a multiple of 8 bytes */
 
 /* work descriptors: one per work-group */
-typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* JD_WG_SEGS segments from seg0 */
+typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 segments of image img from seg0;
+                                                                   JD_WG_WAVES consecutive entries form a work-group */
+#define JD_WG_WAVES    (JD_WG_SEGS / 64u)
+#define JD_NO_WAVE     0xFFFFFFFFu                             /* seg0 of a padding entry */
 typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of jd_plan::pix_rows MCU rows from mcu_row */
 typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */
 #define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
@@ -177,7 +180,7 @@ typedef struct {
     uint32_t n_segs_cap;     /* total segment capacity */
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
-    jd_huff_wg *wwg; uint32_t n_wwg;   /* same segments in groups of JD_WWG_SEGS */
+    jd_huff_wg *wwg; uint32_t n_wwg;   /* the same list (JD_WWG_SEGS == JD_WG_SEGS) */
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
     uint32_t pwg_mode_first[4]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
     jd_raw_wg *rwg;  uint32_t n_rwg;

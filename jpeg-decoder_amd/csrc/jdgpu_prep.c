@@ -99,18 +99,25 @@ typedef struct {
     const jd_lut *lut[JD_LUT_CACHE];
 } lut_cache;
 
-static int lut_build_cached(lut_cache *c, const jdgpu_huff_spec *spec, int is_dc, jd_lut *out) {
+/* *id: which distinct table of the plan this is (-1: the cache is full, identity unknown) */
+static int lut_build_cached(lut_cache *c, const jdgpu_huff_spec *spec, int is_dc, jd_lut *out, int *id) {
     for (unsigned i = 0; i < c->n; ++i)
         if (c->is_dc[i] == is_dc && (c->spec[i] == spec || memcmp(c->spec[i], spec, sizeof *spec) == 0)) {
             memcpy(out, c->lut[i], sizeof *out);
+            *id = (int)i;
             return c->rc[i];
         }
     int rc = jd_lut_build(spec, is_dc, out);
+    *id = -1;
     if (c->n < JD_LUT_CACHE) {
-        c->is_dc[c->n] = is_dc; c->rc[c->n] = rc; c->spec[c->n] = spec; c->lut[c->n] = out; ++c->n;
+        c->is_dc[c->n] = is_dc; c->rc[c->n] = rc; c->spec[c->n] = spec; c->lut[c->n] = out; *id = (int)c->n; ++c->n;
     }
     return rc;
 }
+
+/* What the Huffman kernels keep in LDS for a work-group: the lookup tables of the slots and the
+ * per-unit descriptors.  Images with equal keys may share a work-group (one wave each). */
+typedef struct { int8_t lut_id[JD_LUT_SLOTS]; uint8_t bpm, comp[JD_MAX_BPM], dc[JD_MAX_BPM], ac[JD_MAX_BPM]; } table_key;
 
 /* ---- gathering the scans into one staging buffer ------------------------------------------------
  * 1.5 GB for a 4096 x 1080p batch: a single thread spends ~300 ms in first-touch page faults and
@@ -159,9 +166,11 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
     if (!P->img || !P->luts) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
 
     lut_cache cache; cache.n = 0;
+    table_key *keys = calloc(n ? n : 1, sizeof *keys);
+    if (!keys) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
     size_t raw = 0, clean = 0, pix = 0;
     uint64_t blk = 0;
-    uint32_t segs = 0, ivls = 0, nh = 0, np = 0, nr = 0, nu = 0, nw = 0;
+    uint32_t segs = 0, ivls = 0, np = 0, nr = 0, nu = 0;
     for (size_t i = 0; i < n; ++i) {
         const jdgpu_image_desc *d = &descs[i];
         jd_image *im = &P->img[i];
@@ -200,14 +209,17 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         unsigned nslots = 0, b = 0;
         for (unsigned c = 0; c < nc; ++c) {
             unsigned td = d->comp[c].Td, ta = d->comp[c].Ta;
+            int id;
             if (slot_of[0][td] < 0) {
                 slot_of[0][td] = (int)nslots;
-                if (lut_build_cached(&cache, &d->huff[0][td], 1, &P->luts[im->lut_off + nslots])) ok = 0;
+                if (lut_build_cached(&cache, &d->huff[0][td], 1, &P->luts[im->lut_off + nslots], &id)) ok = 0;
+                keys[i].lut_id[nslots] = (int8_t)(id < 0 ? -1 : id + 1);
                 ++nslots;
             }
             if (slot_of[1][ta] < 0) {
                 slot_of[1][ta] = (int)nslots;
-                if (lut_build_cached(&cache, &d->huff[1][ta], 0, &P->luts[im->lut_off + nslots])) ok = 0;
+                if (lut_build_cached(&cache, &d->huff[1][ta], 0, &P->luts[im->lut_off + nslots], &id)) ok = 0;
+                keys[i].lut_id[nslots] = (int8_t)(id < 0 ? -1 : id + 1);
                 ++nslots;
             }
             im->comp_H[c] = d->comp[c].H; im->comp_V[c] = d->comp[c].V;
@@ -216,10 +228,12 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
                 for (unsigned h = 0; h < d->comp[c].H; ++h, ++b) {
                     im->blk_comp[b] = (uint8_t)c; im->blk_h[b] = (uint8_t)h; im->blk_v[b] = (uint8_t)v;
                     im->blk_dc[b] = (uint8_t)slot_of[0][td]; im->blk_ac[b] = (uint8_t)slot_of[1][ta];
+                    keys[i].comp[b] = (uint8_t)c; keys[i].dc[b] = im->blk_dc[b]; keys[i].ac[b] = im->blk_ac[b];
                 }
         }
         if (!ok) { im->ncomp = 0; continue; }
         im->bpm = (uint8_t)b;
+        keys[i].bpm = (uint8_t)b;
         {
             int std_ids = nc == 3 && d->comp[0].id == 1 && d->comp[1].id == 2 && d->comp[2].id == 3;
             int c11 = d->comp[1].H == 1 && d->comp[1].V == 1 && d->comp[2].H == 1 && d->comp[2].V == 1;
@@ -249,8 +263,6 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         im->n_chunks = (uint32_t)((d->scan_len + JD_RAW_CHUNK - 1) / JD_RAW_CHUNK);
         nu += im->n_intervals + 1; nr += im->n_chunks;
         segs += im->seg_cap; ivls += im->n_intervals; blk += im->n_blocks;
-        nh += (im->seg_cap + JD_WG_SEGS - 1) / JD_WG_SEGS;
-        nw += (im->seg_cap + JD_WWG_SEGS - 1) / JD_WWG_SEGS;
         uint32_t strip = JD_STRIP_PX / (8u * maxH);
         np += im->mcus_y * ((im->mcus_x + strip - 1) / strip); /* single-row strips: regrouped below */
     }
@@ -261,22 +273,67 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         uint32_t rows = np / 8192u;
         P->pix_rows = rows < 1 ? 1 : rows > JD_PIX_ROWS_MAX ? JD_PIX_ROWS_MAX : rows;
     }
-    P->n_hwg = nh; P->n_pwg = np; P->n_rwg = nr; P->n_u = nu;
+    P->n_pwg = np; P->n_rwg = nr; P->n_u = nu;
     P->rwg = calloc(nr ? nr : 1, sizeof *P->rwg);
-    P->n_wwg = nw;
-    P->wwg = calloc(nw ? nw : 1, sizeof *P->wwg);
     P->raw = NULL; /* staging memory comes from the caller: jd_plan_gather() */
-    P->hwg = calloc(nh ? nh : 1, sizeof *P->hwg);
     P->pwg = calloc(np ? np : 1, sizeof *P->pwg);
-    if (!P->hwg || !P->pwg || !P->rwg || !P->wwg) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
-    nh = np = nr = nw = 0;
+    if (!P->pwg || !P->rwg) { free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+    np = nr = 0;
     for (size_t i = 0; i < n; ++i) {
         jd_image *im = &P->img[i];
         if (!im->ncomp) continue;
         for (uint32_t ch = 0; ch < im->n_chunks; ++ch) { P->rwg[nr].img = (uint32_t)i; P->rwg[nr].chunk = ch; ++nr; }
-        for (uint32_t s = 0; s < im->seg_cap; s += JD_WG_SEGS) { P->hwg[nh].img = (uint32_t)i; P->hwg[nh].seg0 = s; ++nh; }
-        for (uint32_t s = 0; s < im->seg_cap; s += JD_WWG_SEGS) { P->wwg[nw].img = (uint32_t)i; P->wwg[nw].seg0 = s; ++nw; }
     }
+    /* Huffman work-groups: JD_WG_WAVES waves of 64 segments, one descriptor per wave.  The waves
+     * of a work-group share the tables in LDS, so they may belong to different images only when
+     * those images have the same table key; images are emitted group by group (groups in order
+     * of first appearance, at most MAXG shared ones; an image whose tables fell out of the
+     * cache, or beyond MAXG groups, stands alone) and a work-group is padded at a group's end.
+     * A 1080p image fills its 3 work-groups alone; thumbnails of one encoder pack 4 per group. */
+    {
+        enum { MAXG = 64 };
+        size_t rep[MAXG]; uint32_t ngrp = 0;
+        int32_t *grp = malloc((n ? n : 1) * sizeof *grp);
+        uint32_t *cnt = calloc(n + MAXG + 1, sizeof *cnt), nsolo = 0;
+        if (!grp || !cnt) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+        for (size_t i = 0; i < n; ++i) {
+            grp[i] = -1;
+            if (!P->img[i].ncomp) continue;
+            int known = 1;
+            for (unsigned k = 0; k < JD_LUT_SLOTS; ++k) known &= keys[i].lut_id[k] >= 0;
+            int32_t g = -1;
+            for (uint32_t q = 0; known && q < ngrp; ++q)
+                if (memcmp(&keys[rep[q]], &keys[i], sizeof keys[i]) == 0) { g = (int32_t)q; break; }
+            if (g < 0 && known && ngrp < MAXG) { rep[ngrp] = i; g = (int32_t)ngrp++; }
+            grp[i] = g < 0 ? (int32_t)(MAXG + nsolo++) : g;   /* solo images: a group each */
+            cnt[grp[i]] += (P->img[i].seg_cap + 63u) / 64u;
+        }
+        /* first descriptor of every group, work-group aligned */
+        uint32_t total = 0;
+        for (uint32_t g = 0; g < MAXG + nsolo; ++g) {
+            uint32_t c = cnt[g];
+            cnt[g] = total;
+            total += (c + JD_WG_WAVES - 1) / JD_WG_WAVES * JD_WG_WAVES;
+        }
+        P->n_hwg = P->n_wwg = total / JD_WG_WAVES;
+        P->hwg = malloc((total ? total : 1) * sizeof *P->hwg);
+        P->wwg = malloc((total ? total : 1) * sizeof *P->wwg);
+        if (!P->hwg || !P->wwg) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+        for (uint32_t k = 0; k < total; ++k) { P->hwg[k].img = 0; P->hwg[k].seg0 = JD_NO_WAVE; }
+        for (size_t i = 0; i < n; ++i) {
+            if (grp[i] < 0) continue;
+            for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
+                uint32_t k = cnt[grp[i]]++;
+                P->hwg[k].img = (uint32_t)i; P->hwg[k].seg0 = sg;
+            }
+        }
+        /* padding descriptors name an image of their own work-group (its tables are staged) */
+        for (uint32_t k = 0; k < total; ++k)
+            if (P->hwg[k].seg0 == JD_NO_WAVE) P->hwg[k].img = P->hwg[k - k % JD_WG_WAVES].img;
+        memcpy(P->wwg, P->hwg, total * sizeof *P->hwg);
+        free(grp); free(cnt);
+    }
+    free(keys);
     /* pixel work-groups, grouped by layout (one kernel instantiation each) */
     for (uint32_t mode = 0; mode < 3; ++mode) {
         P->pwg_mode_first[mode] = np;

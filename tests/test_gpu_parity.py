@@ -435,6 +435,47 @@ def test_torch_views_alias_the_output(pkg, dec):
     assert np.array_equal(ragged.tensor(1).cpu().numpy(), ragged.pixels(1))
 
 
+def _with_extra_ac_symbol(data, value):
+    """the same stream with one more (never used) symbol of length 16 in the luma AC table: every
+    existing code stays what it was, but the table -- and its flattened form -- is a different one"""
+    at = 0
+    while True:
+        at = data.index(b"\xff\xc4", at)
+        if data[at + 4] == 0x10:
+            break
+        at += 2
+    ln = int.from_bytes(data[at + 2:at + 4], "big")
+    seg = bytearray(data[at:at + 2 + ln])
+    seg[5 + 15] += 1                     # one more code of length 16
+    seg += bytes([value])
+    seg[2:4] = (ln + 1).to_bytes(2, "big")
+    return data[:at] + bytes(seg) + data[at + 2 + ln:]
+
+
+def test_work_groups_shared_between_images_only_when_tables_match(pkg, dec, oracle):
+    """Small images with identical tables share a Huffman work-group (one wave each); images with
+    different tables must not.  100 thumbnails, each with its own luma AC table (more distinct
+    tables than the plan's cache holds and more table groups than it shares), interleaved with
+    thumbnails that do share, grayscale ones and two reference examples with optimised tables."""
+    unused = [r << 4 | sz for r in range(16) for sz in range(11, 16)] + [0x10 * r for r in range(1, 15)]
+    files = []
+    for v in range(100):
+        w, h = 40 + 8 * (v % 7), 24 + 8 * (v % 5)
+        base = pkg.synth.make_jpeg(w, h, seed=500 + v, quality=60 + v % 40, subsamp=v % 2, restart_mcus=(v % 3) * 2)
+        files.append(_with_extra_ac_symbol(base, unused[v % len(unused)]))
+        files.append(pkg.synth.make_jpeg(w, h, seed=900 + v, quality=70, subsamp=v % 2))
+        if v % 10 == 0:
+            files.append(pkg.synth.make_jpeg(w, h, seed=v, quality=70, subsamp=4))
+        if v % 25 == 0:
+            files.append(golden_stream("ex_no_subsampling_lake"))
+            files.append(golden_stream("ex_birb"))
+    d0, d1 = pkg.parse(files[0]), pkg.parse(files[2])
+    assert bytes(d0.huff[1][0].counts) != bytes(d1.huff[1][0].counts)
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
