@@ -93,6 +93,11 @@ enum {
 int         jdgpu_device_count(void);
 int         jdgpu_init(int device);          /* bind the calling process to a device; idempotent */
 const char *jdgpu_last_error(void);          /* thread-local text of the last failure */
+/* Device buffers of destroyed batches are kept for the next jdgpu_batch_create (allocating and
+ * freeing tens of GB per batch would stall a caller that creates one batch while another
+ * decodes); this releases what is cached.  Bound: JDGPU_POOL_MB (default 131072, 0 = no cache).
+ * No counterpart in the reference (its only buffer is the caller's malloc, src/test.c:28). */
+void        jdgpu_trim(void);
 
 /* ---- host-side header parsing on a whole file in memory ---------------------------------
  * jpeg_read_info (src/jpeg.c:23-58) over a buffer, flattened into a descriptor whose `scan`

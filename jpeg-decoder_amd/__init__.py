@@ -24,7 +24,7 @@ OUT_RGB, OUT_YCBCR, PROFILE, HOST_PREP, OUT_4BYTE, OUT_PLANAR = 0, 1, 2, 4, 8, 1
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 
 EXPORTS = [
-    "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_parse_file", "jdgpu_parse_files",
+    "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_trim", "jdgpu_parse_file", "jdgpu_parse_files",
     "jdgpu_batch_create", "jdgpu_batch_decode", "jdgpu_batch_sync", "jdgpu_batch_destroy",
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
@@ -82,6 +82,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
     L.jdgpu_last_error.restype = C.c_char_p
+    L.jdgpu_trim.restype = None
     L.jdgpu_parse_file.argtypes = [vp, sz, C.POINTER(ImageDesc)]
     L.jdgpu_parse_files.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(ImageDesc),
                                     C.POINTER(C.c_int), C.c_uint]
@@ -368,6 +369,11 @@ def rgb_to_ycbcr(img):
 
 def segment_bytes():
     return int(lib().jdgpu_segment_bytes())
+
+
+def trim():
+    """release the device buffers cached from destroyed batches"""
+    lib().jdgpu_trim()
 
 
 def device_count():

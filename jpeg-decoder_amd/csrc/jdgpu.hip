@@ -1426,11 +1426,92 @@ static int ensure_device() {
     return jdgpu_init(0);
 }
 
+/* Device buffers are recycled.  A 4096 x 1080p batch holds ~56 GB; hipMalloc of that takes from
+ * 2 ms to 0.5 s (measured, the latter while another batch decodes) and hipFree waits for the
+ * whole device, so a loader that creates batch k+1 while batch k decodes would stall on both.
+ * Destroyed batches hand their buffers to a process-wide cache (one process drives one GPU);
+ * a creation takes the smallest cached buffer that is big enough and at most 25 % too big.
+ * The cache is bounded (JDGPU_POOL_MB, default 131072; 0 turns it off), emptied when an
+ * allocation fails, and by jdgpu_trim(). */
+struct PoolBuf { void *p; size_t bytes; };
+static std::mutex g_pool_mu;
+static std::vector<PoolBuf> g_pool_free;
+static std::vector<PoolBuf> g_pool_live;
+static size_t g_pool_cached = 0;
+static size_t pool_limit() {
+    static size_t lim = [] {
+        const char *e = getenv("JDGPU_POOL_MB");
+        return (size_t)(e ? strtoull(e, nullptr, 10) : 131072ull) << 20;
+    }();
+    return lim;
+}
+static void pool_trim_locked(size_t keep) {
+    while (g_pool_cached > keep && !g_pool_free.empty()) { /* oldest first */
+        hipFree(g_pool_free.front().p);
+        g_pool_cached -= g_pool_free.front().bytes;
+        g_pool_free.erase(g_pool_free.begin());
+    }
+}
+static int pool_alloc(void **out, size_t bytes) {
+    *out = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool_free.size();
+        for (size_t i = 0; i < g_pool_free.size(); ++i) {
+            const size_t c = g_pool_free[i].bytes;
+            if (c >= bytes && c <= bytes + bytes / 4 + 4096 && (best == g_pool_free.size() || c < g_pool_free[best].bytes)) best = i;
+        }
+        if (best != g_pool_free.size()) {
+            PoolBuf b = g_pool_free[best];
+            g_pool_free.erase(g_pool_free.begin() + (long)best);
+            g_pool_cached -= b.bytes;
+            g_pool_live.push_back(b);
+            *out = b.p;
+            return JDGPU_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { /* memory held by the cache may be what is missing */
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+        *out = nullptr;
+        snprintf(g_err, sizeof g_err, "hipMalloc(%zu bytes) -> %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? JDGPU_ERR_NOMEM : JDGPU_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live.push_back({*out, bytes});
+    return JDGPU_OK;
+}
+/* the caller has made sure that nothing in flight still uses the buffer */
+static void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool_live.size(); ++i)
+        if (g_pool_live[i].p == p) {
+            PoolBuf b = g_pool_live[i];
+            g_pool_live[i] = g_pool_live.back();
+            g_pool_live.pop_back();
+            if (b.bytes > pool_limit()) { hipFree(b.p); return; }
+            g_pool_free.push_back(b);
+            g_pool_cached += b.bytes;
+            pool_trim_locked(pool_limit());
+            return;
+        }
+    hipFree(p); /* not ours: cannot happen, but never leak */
+}
+extern "C" void jdgpu_trim(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_trim_locked(0);
+}
+
 template <class T>
 static int dalloc(T **p, size_t count) {
-    *p = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)));
-    return JDGPU_OK;
+    return pool_alloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != JDGPU_OK) { jdgpu_batch_destroy(b); return rc_; } } while (0)
@@ -1447,11 +1528,13 @@ static int dalloc(T **p, size_t count) {
 
 extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     if (!b) return;
-    hipFree(b->d_raw); hipFree(b->d_clean); hipFree(b->d_pix); hipFree(b->d_img); hipFree(b->d_luts);
-    hipFree(b->d_seg_info); hipFree(b->d_st_in); hipFree(b->d_st_exit); hipFree(b->d_list);
-    hipFree(b->d_list_cnt); hipFree(b->d_status); hipFree(b->d_cnt); hipFree(b->d_cp_state); hipFree(b->d_cp_val);
-    hipFree(b->d_start_dc); hipFree(b->d_start_blk); hipFree(b->d_coef); hipFree(b->d_hwg); hipFree(b->d_pwg);
-    hipFree(b->d_rwg); hipFree(b->d_wwg); hipFree(b->d_chunk_cnt); hipFree(b->d_chunk_base); hipFree(b->d_ivl_u); hipFree(b->d_ivl_seg);
+    /* the buffers go back to the cache and may be handed out at once: nothing of this batch may
+     * still be running (hipFree used to wait for the whole device here) */
+    if (b->stream) hipStreamSynchronize(b->stream);
+    void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
+                    b->d_list_cnt, b->d_status, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
+                    b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg};
+    for (void *p : bufs) pool_free(p);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
     jd_plan_free(&b->plan);
@@ -1551,10 +1634,11 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
-    if (trace) { HIPTRY(hipDeviceSynchronize()); fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
-    HIPTRY(hipMemset(b->d_pix, 0, (size_t)P.pix_bytes + 256));
-    HIPTRY(hipMemset(b->d_status, 0, (n ? n : 1) * 4));
-    if (trace) { HIPTRY(hipDeviceSynchronize()); fprintf(stderr, "[jdgpu] output clear %.1f ms\n", now() - t0); }
+    if (trace) { fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
+    /* on the batch's own stream: ordered before its first decode without waiting for other batches */
+    HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
+    HIPTRY(hipMemsetAsync(b->d_status, 0, (n ? n : 1) * 4, b->stream));
+    if (trace) { HIPTRY(hipStreamSynchronize(b->stream)); fprintf(stderr, "[jdgpu] output clear %.1f ms\n", now() - t0); }
     /* the host copies of the bulky arrays are not needed any more */
     free(P.clean); P.clean = nullptr; free(P.luts); P.luts = nullptr;
     *out = b;

@@ -476,6 +476,29 @@ def test_work_groups_shared_between_images_only_when_tables_match(pkg, dec, orac
         _check_against_oracle(pkg, oracle, out, i, f)
 
 
+def test_recycled_device_buffers_hold_no_stale_state(pkg, dec, oracle):
+    """destroyed batches hand their device buffers to the next creation (jdgpu_trim releases
+    them): a batch that inherits buffers full of another batch's coefficients, states and pixels
+    must decode as if they were fresh -- including an image that fails half way"""
+    rng = np.random.default_rng(5)
+    noise = [pkg.synth.encode_rgb(rng.integers(0, 256, (200, 264, 3), dtype=np.uint8), quality=95, subsamp=s) for s in (0, 1)]
+    small = [pkg.synth.make_jpeg(w, h, seed=w, quality=75, subsamp=ss, restart_mcus=ri)
+             for (w, h, ss, ri) in ((264, 200, 1, 0), (200, 264, 0, 3), (130, 90, 2, 0), (264, 200, 4, 0))]
+    cut = small[0][:len(small[0]) * 2 // 3]
+    for rep in range(3):
+        a = dec.decode(noise * 3)
+        for i in range(2):
+            _check_against_oracle(pkg, oracle, a, i, noise[i])
+        a.close()
+        b = dec.decode(small + [cut])          # same byte sizes or smaller: takes a's buffers
+        for i, f in enumerate(small):
+            _check_against_oracle(pkg, oracle, b, i, f)
+        assert b.status(len(small)) & pkg.IMG_EOF
+        b.close()
+        if rep == 1:
+            pkg.trim()
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
