@@ -10,7 +10,7 @@ pkg = ge.load_package()
 import bench
 
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-P = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+P = min(2, int(sys.argv[2]) if len(sys.argv) > 2 else 2)   # each batch in flight holds ~56 GB of HBM at 4096 x 1080p
 BS = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 files = bench.make_files(pkg, "c3", 64, 0)
 dec = pkg.Decoder(0)
@@ -26,8 +26,12 @@ def producer():
                 return
             todo.pop()
         t = time.perf_counter()
-        descs = pkg.parse_many(batch_files)
-        b = pkg.Batch(descs)
+        try:
+            descs = pkg.parse_many(batch_files)
+            b = pkg.Batch(descs)
+        except Exception as e:      # e.g. out of device memory with too many batches in flight
+            q.put((e, 0.0))
+            return
         q.put((b, time.perf_counter() - t))
 
 threads = [threading.Thread(target=producer, daemon=True) for _ in range(P)]
@@ -37,6 +41,8 @@ t0 = None
 create_s = []
 while done < NB + 2:
     b, tc = q.get()
+    if isinstance(b, Exception):
+        raise SystemExit(f"a producer failed: {b}")
     if done == 2:            # the first two batches warm up (pinned staging allocation, code load)
         t0 = time.perf_counter(); pixels = 0
     b.decode()
