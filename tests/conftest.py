@@ -82,3 +82,18 @@ def fuzzed_streams(oracle, count=120, seed=2024):
             g[pos:pos + 2] = bytes([0xFF, 0xD0 + int(rng.integers(8))])
         files.append(bytes(g))
     return files
+
+
+def with_component_ids(data, ids):
+    """the same stream with its three components numbered `ids` (a permutation of 1, 2, 3) in
+    SOF0 and SOS: component k's samples then land in channel ids[k] - 1 (src/decoding.c:107)"""
+    b = bytearray(data)
+    f = data.index(b"\xff\xc0")
+    assert b[f + 9] == 3
+    for k in range(3):
+        b[f + 10 + 3 * k] = ids[k]
+    sos = data.index(b"\xff\xda")
+    assert b[sos + 4] == 3
+    for k in range(3):
+        b[sos + 5 + 2 * k] = ids[k]
+    return bytes(b)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, all_golden_names, dri_names, fuzzed_streams, golden_arrays, golden_stream,
-                      load_pkg, plain_names)
+                      load_pkg, plain_names, with_component_ids)
 
 pytestmark = pytest.mark.gpu
 
@@ -497,6 +497,25 @@ def test_recycled_device_buffers_hold_no_stale_state(pkg, dec, oracle):
         b.close()
         if rep == 1:
             pkg.trim()
+
+
+def test_permuted_component_ids(pkg, dec, oracle):
+    """components numbered (2,3,1), (3,1,2), (1,3,2): output channel = id - 1
+    (src/decoding.c:107; oracle pinned to the reference for these in tests/test_oracle_golden.py);
+    such streams take the generic instantiation of the pixel kernel"""
+    files = []
+    for ids in ((2, 3, 1), (3, 1, 2), (1, 3, 2)):
+        for name in ("syn_200x136_444_q95", "syn_200x136_420_q50", "syn_96x40_422_q80", "syn_72x96_440_q75"):
+            files.append(with_component_ids(golden_stream(name), ids))
+    for flags, view in ((pkg.OUT_YCBCR, lambda a: a), (pkg.OUT_YCBCR | pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0))):
+        out = dec.decode(files, flags)
+        for i, f in enumerate(files):
+            rc, want = oracle.ycbcr(f)
+            assert rc == 0 and out.status(i) == 0
+            assert np.array_equal(view(out.pixels(i)), want), i
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
 
 
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
