@@ -97,3 +97,25 @@ def with_component_ids(data, ids):
     for k in range(3):
         b[sos + 5 + 2 * k] = ids[k]
     return bytes(b)
+
+
+def with_high_table_ids(data):
+    """the same synthetic stream with its quantisation tables under ids 2 and 3 and its Huffman
+    tables under ids 2 (luma) and 3 (chroma) instead of 0 and 1 -- every id the headers allow
+    (src/parsing.c:42-49, 92-96, 125-126)"""
+    b = bytearray(data)
+    q = data.index(b"\xff\xdb")
+    assert b[q + 4] == 0 and b[q + 4 + 65] == 1
+    b[q + 4], b[q + 4 + 65] = 2, 3
+    f = data.index(b"\xff\xc0")
+    for k in range(b[f + 9]):
+        b[f + 12 + 3 * k] += 2
+    at = 0
+    for _ in range(4):
+        at = data.index(b"\xff\xc4", at)
+        b[at + 4] += 2
+        at += 2
+    sos = data.index(b"\xff\xda")
+    for k in range(b[sos + 4]):
+        b[sos + 6 + 2 * k] += 0x22
+    return bytes(b)

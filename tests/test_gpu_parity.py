@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, all_golden_names, dri_names, fuzzed_streams, golden_arrays, golden_stream,
-                      load_pkg, plain_names, with_component_ids)
+                      load_pkg, plain_names, with_component_ids, with_high_table_ids)
 
 pytestmark = pytest.mark.gpu
 
@@ -516,6 +516,19 @@ def test_permuted_component_ids(pkg, dec, oracle):
     out = dec.decode(files)
     for i, f in enumerate(files):
         _check_against_oracle(pkg, oracle, out, i, f)
+
+
+def test_high_table_ids(pkg, dec, oracle):
+    """tables under ids 2 and 3, alone and combined with renumbered components, next to the plain
+    streams (different table keys: no shared work-groups between them)"""
+    files = []
+    for name in ("syn_200x136_444_q95", "syn_200x136_420_q50", "syn_96x40_422_q80"):
+        plain = golden_stream(name)
+        files += [with_high_table_ids(plain), plain, with_component_ids(with_high_table_ids(plain), (3, 1, 2))]
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    assert np.array_equal(out.pixels(0), out.pixels(1))
 
 
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
