@@ -1157,9 +1157,13 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
     /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
-    constexpr uint32_t PLANE1 = MODE == JD_PIX_420 ? 16u * PIX_ROW : MODE == JD_PIX_444 ? 8u * PIX_ROW : PLANE_BYTES;
-    constexpr uint32_t PLANE2 = PLANE1 + (MODE == JD_PIX_GENERIC ? PLANE_BYTES : 8u * PIX_ROW);
-    constexpr uint32_t TILE_BYTES = PLANE2 + (MODE == JD_PIX_GENERIC ? PLANE_BYTES : 8u * PIX_ROW);
+    /* the layouts with an instantiation of their own: luma HSH+1 x VSH+1 units per MCU, chroma 1x1 */
+    constexpr bool FAST = MODE != JD_PIX_GENERIC, GRAY = MODE == JD_PIX_GRAY;
+    constexpr uint32_t HSH = (MODE == JD_PIX_420 || MODE == JD_PIX_422) ? 1u : 0u;   /* chroma shared by 2 columns */
+    constexpr uint32_t VSH = (MODE == JD_PIX_420 || MODE == JD_PIX_440) ? 1u : 0u;   /* ... by 2 rows */
+    constexpr uint32_t PLANE1 = FAST ? (8u << VSH) * PIX_ROW : PLANE_BYTES;
+    constexpr uint32_t PLANE2 = PLANE1 + (FAST ? (GRAY ? 0u : 8u * PIX_ROW) : PLANE_BYTES);
+    constexpr uint32_t TILE_BYTES = PLANE2 + (FAST ? (GRAY ? 0u : 8u * PIX_ROW) : PLANE_BYTES);
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
     __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
@@ -1169,9 +1173,9 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const jd_image &im = imgs[wg.img];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     /* one instantiation per pixel layout: the common ones get their geometry as constants */
-    const uint32_t maxH = MODE == JD_PIX_420 ? 2u : MODE == JD_PIX_444 ? 1u : im.maxH;
-    const uint32_t maxV = MODE == JD_PIX_420 ? 2u : MODE == JD_PIX_444 ? 1u : im.maxV;
-    const uint32_t bpm = MODE == JD_PIX_420 ? 6u : MODE == JD_PIX_444 ? 3u : im.bpm;
+    const uint32_t maxH = FAST ? 1u << HSH : im.maxH;
+    const uint32_t maxV = FAST ? 1u << VSH : im.maxV;
+    const uint32_t bpm = FAST ? (GRAY ? 1u : (1u << (HSH + VSH)) + 2u) : im.bpm;
     const uint32_t sub_mcus = SUB_PX / (8u * maxH);
     for (uint32_t i = tid; i < 256; i += 64 * JD_PIX_WAVES) s_q[i >> 6][i & 63u] = im.quant[i >> 6][i & 63u];
     if (tid < JD_MAX_BPM) {
@@ -1277,39 +1281,42 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         if (draws) {
             /* 24-bit multiplies for the row offsets and the pixel index (rows, widths < 2^16): a
              * full 32-bit or 64-bit multiply costs as much as four plain instructions */
-            if (MODE == JD_PIX_420) {
-                /* lane: 4 pixels x 2 rows sharing one chroma row */
-                /* chroma rows of lane group rq: {0,2}, {4,6}, {1,3}, {5,7} -- the two groups that
-                 * share a 32-lane LDS access read luma rows 8 apart (16 banks apart: no conflict;
-                 * 2 apart would overlap on 12 of 16 banks).  offC is carried: the compiler makes
+            if (FAST) {
+                /* lane: 4 pixels of one chroma row = 1 or 2 (VSH) luma rows; two chroma rows per lane
+                 * group rq.  With vertical sharing: {0,2}, {4,6}, {1,3}, {5,7} -- the two groups
+                 * that share a 32-lane LDS access then read luma rows 8 apart, 16 banks: no conflict
+                 * (2 apart would overlap on 12 of 16 banks).  offC is carried: the compiler makes
                  * rp * 72 a full multiply */
-                const uint32_t rp0 = (rq & 1u) * 4u + (rq >> 1);
-                uint32_t offC = rp0 * PIX_ROW + 2u * g;
-                for (uint32_t rp = rp0; rp < rp0 + 4u && 2u * rp < rows; rp += 2, offC += 2u * PIX_ROW) {
-                    uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[offC]);
-                    uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[offC]);
-                    const uint32_t cbv[4] = {cbp & 255u, cbp & 255u, cbp >> 8, cbp >> 8};
-                    const uint32_t crv[4] = {crp & 255u, crp & 255u, crp >> 8, crp >> 8};
+                const uint32_t rp0 = VSH ? (rq & 1u) * 4u + (rq >> 1) : rq;
+                constexpr uint32_t STEP = VSH ? 2u : 4u;      /* without vertical sharing: rows rq, rq + 4 (1 apart in a group) */
+                constexpr uint32_t CB = 4u >> HSH;            /* chroma bytes under the lane's 4 pixels */
+                uint32_t offC = rp0 * PIX_ROW + CB * g;
+                for (uint32_t rp = rp0; rp < rp0 + 2u * STEP && (rp << VSH) < rows; rp += STEP, offC += STEP * PIX_ROW) {
+                    uint32_t cbv[4], crv[4];
+                    if (GRAY) {
 #pragma unroll
-                    for (uint32_t dy = 0; dy < 2; ++dy) {
-                        uint32_t r = 2u * rp + dy;
+                        for (int i = 0; i < 4; ++i) cbv[i] = crv[i] = 128u; /* absent channels: neutral */
+                    } else if (HSH) {
+                        uint32_t cbp = *reinterpret_cast<const uint16_t *>(&tB[offC]);
+                        uint32_t crp = *reinterpret_cast<const uint16_t *>(&tR[offC]);
+                        cbv[0] = cbv[1] = cbp & 255u; cbv[2] = cbv[3] = cbp >> 8;
+                        crv[0] = crv[1] = crp & 255u; crv[2] = crv[3] = crp >> 8;
+                    } else {
+                        uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[offC]);
+                        uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[offC]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { cbv[i] = (cb4 >> (8 * i)) & 255u; crv[i] = (cr4 >> (8 * i)) & 255u; }
+                    }
+                    const uint32_t offY = ((offC - CB * g) << VSH) + 4u * g;   /* luma row (rp << VSH), column 4g */
+#pragma unroll
+                    for (uint32_t dy = 0; dy < (1u << VSH); ++dy) {
+                        uint32_t r = (rp << VSH) + dy;
                         if (r < rows) {
-                            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[2u * offC + dy * PIX_ROW]);
-                            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 2);
+                            uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[offY + dy * PIX_ROW]);
+                            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, HSH ? 2 : 4);
                             store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
                         }
                     }
-                }
-            } else if (MODE == JD_PIX_444) {
-                uint32_t off = rq * PIX_ROW + 4u * g;
-                for (uint32_t r = rq; r < rows; r += 4, off += 4u * PIX_ROW) {
-                    uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[off]);
-                    uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&tB[off]);
-                    uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&tR[off]);
-                    const uint32_t cbv[4] = {cb4 & 255u, (cb4 >> 8) & 255u, (cb4 >> 16) & 255u, cb4 >> 24};
-                    const uint32_t crv[4] = {cr4 & 255u, (cr4 >> 8) & 255u, (cr4 >> 16) & 255u, cr4 >> 24};
-                    Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, 4);
-                    store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
                 }
             } else {
                 /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
@@ -1645,20 +1652,21 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     return JDGPU_OK;
 }
 
+template <bool OUT_YCBCR, uint32_t MODE, uint32_t FMT>
+static void launch_pixel_mode(jdgpu_batch *b, hipStream_t st) {
+    const uint32_t *f = b->plan.pwg_mode_first;
+    if (f[MODE + 1] > f[MODE])
+        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, MODE, FMT>), dim3(f[MODE + 1] - f[MODE]), dim3(64 * JD_PIX_WAVES), 0, st,
+                           b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->plan.pix_rows);
+}
 template <bool OUT_YCBCR, uint32_t FMT>
 static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
-    jd_plan &P = b->plan;
-    const dim3 block(64 * JD_PIX_WAVES);
-    const uint32_t *f = P.pwg_mode_first;
-    if (f[JD_PIX_GENERIC + 1] > f[JD_PIX_GENERIC])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_GENERIC, FMT>), dim3(f[JD_PIX_GENERIC + 1] - f[JD_PIX_GENERIC]), block, 0, st,
-                           b->d_img, b->d_pwg + f[JD_PIX_GENERIC], b->d_coef, b->d_pix, P.pix_rows);
-    if (f[JD_PIX_420 + 1] > f[JD_PIX_420])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_420, FMT>), dim3(f[JD_PIX_420 + 1] - f[JD_PIX_420]), block, 0, st,
-                           b->d_img, b->d_pwg + f[JD_PIX_420], b->d_coef, b->d_pix, P.pix_rows);
-    if (f[JD_PIX_444 + 1] > f[JD_PIX_444])
-        hipLaunchKernelGGL((k_pixel<OUT_YCBCR, JD_PIX_444, FMT>), dim3(f[JD_PIX_444 + 1] - f[JD_PIX_444]), block, 0, st,
-                           b->d_img, b->d_pwg + f[JD_PIX_444], b->d_coef, b->d_pix, P.pix_rows);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_GENERIC, FMT>(b, st);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_420, FMT>(b, st);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_444, FMT>(b, st);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_422, FMT>(b, st);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_440, FMT>(b, st);
+    launch_pixel_mode<OUT_YCBCR, JD_PIX_GRAY, FMT>(b, st);
 }
 template <bool OUT_YCBCR>
 static void launch_pixel_formats(jdgpu_batch *b, hipStream_t st) {

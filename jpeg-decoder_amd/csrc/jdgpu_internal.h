@@ -165,6 +165,10 @@ typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK
 #define JD_PIX_GENERIC 0u
 #define JD_PIX_420 1u     /* ids 1,2,3 in scan order, Y 2x2, Cb/Cr 1x1 */
 #define JD_PIX_444 2u     /* ids 1,2,3 in scan order, all 1x1 */
+#define JD_PIX_422 3u     /* ... Y 2x1 */
+#define JD_PIX_440 4u     /* ... Y 1x2 */
+#define JD_PIX_GRAY 5u    /* one component, id 1, 1x1 */
+#define JD_PIX_MODES 6u
 
 /* ---- host preparation (jdgpu_prep.c) -------------------------------------------------------- */
 
@@ -182,7 +186,7 @@ typedef struct {
     jd_huff_wg *hwg; uint32_t n_hwg;
     jd_huff_wg *wwg; uint32_t n_wwg;   /* the same list (JD_WWG_SEGS == JD_WG_SEGS) */
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
-    uint32_t pwg_mode_first[4]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
+    uint32_t pwg_mode_first[JD_PIX_MODES + 1]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
     jd_raw_wg *rwg;  uint32_t n_rwg;
     uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;

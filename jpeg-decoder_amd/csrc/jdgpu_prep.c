@@ -240,6 +240,9 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
             im->pix_mode = JD_PIX_GENERIC;
             if (std_ids && c11 && d->comp[0].H == 2 && d->comp[0].V == 2) im->pix_mode = JD_PIX_420;
             if (std_ids && c11 && d->comp[0].H == 1 && d->comp[0].V == 1) im->pix_mode = JD_PIX_444;
+            if (std_ids && c11 && d->comp[0].H == 2 && d->comp[0].V == 1) im->pix_mode = JD_PIX_422;
+            if (std_ids && c11 && d->comp[0].H == 1 && d->comp[0].V == 2) im->pix_mode = JD_PIX_440;
+            if (nc == 1 && d->comp[0].id == 1) im->pix_mode = JD_PIX_GRAY;
         }
         for (unsigned t = 0; t < 4; ++t)
             for (unsigned k = 0; k < 64; ++k) im->quant[t][jd_zigzag_to_cm[k]] = d->quant[t][k];
@@ -335,7 +338,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
     }
     free(keys);
     /* pixel work-groups, grouped by layout (one kernel instantiation each) */
-    for (uint32_t mode = 0; mode < 3; ++mode) {
+    for (uint32_t mode = 0; mode < JD_PIX_MODES; ++mode) {
         P->pwg_mode_first[mode] = np;
         for (size_t i = 0; i < n; ++i) {
             jd_image *im = &P->img[i];
@@ -347,7 +350,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
                 }
         }
     }
-    P->pwg_mode_first[3] = np;
+    P->pwg_mode_first[JD_PIX_MODES] = np;
     P->n_pwg = np; /* after grouping rows */
     return JDGPU_OK;
 }
