@@ -531,6 +531,21 @@ def test_high_table_ids(pkg, dec, oracle):
     assert np.array_equal(out.pixels(0), out.pixels(1))
 
 
+def test_extreme_aspect_ratios(pkg, dec, oracle):
+    """the 16-bit limits of the frame header: one pixel row of 65535 columns, one column of 65535
+    rows, long thin strips in every layout, with restart markers"""
+    files = []
+    for (w, h, ss, ri) in ((65535, 1, 0, 0), (1, 65535, 0, 0), (65535, 2, 1, 0), (2, 65535, 1, 7), (65535, 3, 2, 100),
+                           (3, 65535, 3, 0), (65535, 1, 4, 0), (32768, 16, 1, 2048), (16, 32768, 1, 0)):
+        files.append(pkg.synth.make_jpeg(w, h, seed=w % 97 + h % 89, quality=70, subsamp=ss, restart_mcus=ri))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    planar = dec.decode(files[:4], pkg.OUT_PLANAR)
+    for i in range(4):
+        assert np.array_equal(planar.pixels(i), out.pixels(i).transpose(2, 0, 1))
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
