@@ -569,11 +569,12 @@ __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTabl
     return JD_ST_PACK(p - valid, k, b);
 }
 
-__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im, int sel) {
+__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im, int sel,
+                                             uint32_t nslots = JD_LUT_SLOTS) {
     constexpr uint32_t HOT16 = sizeof(jd_lut_hot) / 16, LUT16 = sizeof(jd_lut) / 16;
     const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-    for (uint32_t i = threadIdx.x; i < JD_LUT_SLOTS * HOT16; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < nslots * HOT16; i += blockDim.x)
         dst[i] = src[(i / HOT16) * LUT16 + i % HOT16];
     if (threadIdx.x < JD_MAX_BPM) {
         const uint32_t dcs = im.blk_dc[threadIdx.x], acs = im.blk_ac[threadIdx.x], c = im.blk_comp[threadIdx.x];
@@ -817,7 +818,8 @@ __device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
     return lane * WBUF_BYTES + ((((idx >> 3) + lane) & 7u) << 4) + ((idx & 7u) << 1);
 }
 
-__global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__restrict__ imgs,
+template <uint32_t WAVES, uint32_t SLOTS>
+__global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
                                                            const uint8_t *__restrict__ clean,
                                                            const uint32_t *__restrict__ seg_info,
@@ -829,14 +831,16 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
                                                            int16_t *__restrict__ coef,
                                                            uint32_t *__restrict__ status) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
-    __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[JD_WWG_SEGS * WBUF_BYTES];
-    __shared__ uint32_t s_qblk[JD_WWG_SEGS];   /* per wave: global unit index of the r-th finished unit */
-    __shared__ uint8_t s_qlane[JD_WWG_SEGS];   /* per wave: lane (within the work-group) that holds it */
+    /* <4 waves, 6 table slots>: 51 KB, 3 work-groups = 12 waves per CU; <8, 4> (no image of the
+     * batch uses more than 4 slots): 78 KB, 2 work-groups = 16 waves per CU */
+    __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[SLOTS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[64 * WAVES * WBUF_BYTES];
+    __shared__ uint32_t s_qblk[64 * WAVES];   /* per wave: global unit index of the r-th finished unit */
+    __shared__ uint8_t s_qlane[64 * WAVES];   /* per wave: lane (within the wave) that holds it */
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
     __shared__ uint8_t s_cm[64];
 
-    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)]; /* per wave, see k_huff_first */
+    const jd_huff_wg wg = wgs[blockIdx.x * WAVES + (threadIdx.x >> 6)]; /* per wave, see k_huff_first */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
     if (!__syncthreads_or(wg.seg0 < n_segs)) return;
@@ -844,8 +848,8 @@ __global__ __launch_bounds__(JD_WWG_SEGS) void k_huff_write(const jd_image *__re
     const uint32_t seg = wg.seg0 + wlane;
     const jd_lut *const g_lut = luts + im.lut_off;
     {
-        const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
-        stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, -1);
+        const jd_image &im0 = imgs[wgs[blockIdx.x * WAVES].img];
+        stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, -1, SLOTS);
     }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
@@ -1613,7 +1617,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
     TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
-    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * JD_WG_WAVES));
+    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * P.wwg_waves));
     TRY(dalloc(&b->d_chunk_cnt, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_chunk_base, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_ivl_u, (size_t)P.n_u));
@@ -1640,7 +1644,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     if (trace) { fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
     /* on the batch's own stream: ordered before its first decode without waiting for other batches */
     HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
@@ -1676,6 +1680,18 @@ static void launch_pixel_formats(jdgpu_batch *b, hipStream_t st) {
 }
 static void launch_pixel(jdgpu_batch *b, hipStream_t st) {
     if (b->flags & JDGPU_OUT_YCBCR) launch_pixel_formats<true>(b, st); else launch_pixel_formats<false>(b, st);
+}
+
+static void launch_write(jdgpu_batch *b, hipStream_t st) {
+    jd_plan &P = b->plan;
+    if (P.wwg_waves == JD_WWG_WAVES_BIG)
+        hipLaunchKernelGGL((k_huff_write<JD_WWG_WAVES_BIG, JD_WWG_SLOTS_BIG>), dim3(P.n_wwg), dim3(64 * JD_WWG_WAVES_BIG), 0, st,
+                           b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk,
+                           b->d_start_dc, b->d_coef, b->d_status);
+    else
+        hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS>), dim3(P.n_wwg), dim3(64 * JD_WG_WAVES), 0, st,
+                           b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk,
+                           b->d_start_dc, b->d_coef, b->d_status);
 }
 
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
@@ -1723,9 +1739,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
-    if (P.n_hwg)
-        hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
-                           b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+    if (P.n_hwg) launch_write(b, st);
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
     if (P.n_pwg) {
         launch_pixel(b, st);
@@ -1765,8 +1779,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
             if (clean) break;
         }
         hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
-        hipLaunchKernelGGL(k_huff_write, dim3(P.n_wwg), dim3(JD_WWG_SEGS), 0, s, b->d_img, b->d_luts, b->d_clean, b->d_seg_info,
-                           b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, b->d_start_dc, b->d_coef, b->d_status);
+        launch_write(b, s);
         launch_pixel(b, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));

@@ -24,7 +24,6 @@ extern "C" {
 #define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 512 B  */
 #define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 4096 b */
 #define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group, sync kernels */
-#define JD_WWG_SEGS    256u                   /* ... of the coefficient-write kernel (512 measured slower: ragged last group per image) */
 #define JD_MAX_BPM     12u                    /* data units per MCU: 3 components of at most 2x2 */
 #define JD_LUT_BITS    10u                    /* primary Huffman lookup width */
 #define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
@@ -152,6 +151,8 @@ typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 
                                                                    JD_WG_WAVES consecutive entries form a work-group */
 #define JD_WG_WAVES    (JD_WG_SEGS / 64u)
 #define JD_NO_WAVE     0xFFFFFFFFu                             /* seg0 of a padding entry */
+#define JD_WWG_WAVES_BIG 8u                                    /* write kernel, batches whose images use ... */
+#define JD_WWG_SLOTS_BIG 4u                                    /* ... at most this many table slots */
 typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of jd_plan::pix_rows MCU rows from mcu_row */
 typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */
 #define JD_RAW_CHUNK 4096u /* 256 lanes x 16 bytes */
@@ -184,7 +185,8 @@ typedef struct {
     uint32_t n_segs_cap;     /* total segment capacity */
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
-    jd_huff_wg *wwg; uint32_t n_wwg;   /* the same list (JD_WWG_SEGS == JD_WG_SEGS) */
+    jd_huff_wg *wwg; uint32_t n_wwg;   /* the same waves in work-groups of wwg_waves (write kernel) */
+    uint32_t wwg_waves;
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
     uint32_t pwg_mode_first[JD_PIX_MODES + 1]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
     jd_raw_wg *rwg;  uint32_t n_rwg;

@@ -311,29 +311,48 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
             grp[i] = g < 0 ? (int32_t)(MAXG + nsolo++) : g;   /* solo images: a group each */
             cnt[grp[i]] += (P->img[i].seg_cap + 63u) / 64u;
         }
-        /* first descriptor of every group, work-group aligned */
-        uint32_t total = 0;
-        for (uint32_t g = 0; g < MAXG + nsolo; ++g) {
-            uint32_t c = cnt[g];
-            cnt[g] = total;
-            total += (c + JD_WG_WAVES - 1) / JD_WG_WAVES * JD_WG_WAVES;
-        }
-        P->n_hwg = P->n_wwg = total / JD_WG_WAVES;
-        P->hwg = malloc((total ? total : 1) * sizeof *P->hwg);
-        P->wwg = malloc((total ? total : 1) * sizeof *P->wwg);
-        if (!P->hwg || !P->wwg) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
-        for (uint32_t k = 0; k < total; ++k) { P->hwg[k].img = 0; P->hwg[k].seg0 = JD_NO_WAVE; }
+        /* the write kernel runs 8-wave work-groups when no image of the batch needs more than 4
+         * table slots (2 DC + 2 AC, the usual case): 2 x (64 KB of unit buffers + 11 KB of tables)
+         * fit a CU's LDS, 16 waves per CU instead of 12 */
+        uint32_t max_slots = 0;
         for (size_t i = 0; i < n; ++i) {
-            if (grp[i] < 0) continue;
-            for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
-                uint32_t k = cnt[grp[i]]++;
-                P->hwg[k].img = (uint32_t)i; P->hwg[k].seg0 = sg;
-            }
+            uint32_t ns = 0;
+            for (unsigned k = 0; k < JD_LUT_SLOTS; ++k) ns += keys[i].lut_id[k] != 0;
+            if (P->img[i].ncomp && ns > max_slots) max_slots = ns;
         }
-        /* padding descriptors name an image of their own work-group (its tables are staged) */
-        for (uint32_t k = 0; k < total; ++k)
-            if (P->hwg[k].seg0 == JD_NO_WAVE) P->hwg[k].img = P->hwg[k - k % JD_WG_WAVES].img;
-        memcpy(P->wwg, P->hwg, total * sizeof *P->hwg);
+        uint32_t all_waves = 0;
+        for (uint32_t g = 0; g < MAXG + nsolo; ++g) all_waves += cnt[g];
+        /* ... and only when there are enough waves to fill the chip twice over with them (a batch
+         * of thumbnails spreads better in 4-wave groups: C2 0.68 against 0.79 ms) */
+        const char *force = getenv("JDGPU_WWG_WAVES");   /* tests: "8" / "4" take the other path where it is legal */
+        uint32_t want_big = force ? (uint32_t)(atoi(force) == 8) : (uint32_t)(all_waves >= 8192u);
+        P->wwg_waves = (max_slots <= JD_WWG_SLOTS_BIG && want_big) ? JD_WWG_WAVES_BIG : JD_WG_WAVES;
+        uint32_t *first = malloc((n + MAXG + 1) * sizeof *first);
+        if (!first) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t W = pass ? P->wwg_waves : JD_WG_WAVES;
+            /* first descriptor of every group, work-group aligned */
+            uint32_t total = 0;
+            for (uint32_t g = 0; g < MAXG + nsolo; ++g) {
+                first[g] = total;
+                total += (cnt[g] + W - 1) / W * W;
+            }
+            jd_huff_wg *L = malloc((total ? total : 1) * sizeof *L);
+            if (!L) { free(first); free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+            for (uint32_t k = 0; k < total; ++k) { L[k].img = 0; L[k].seg0 = JD_NO_WAVE; }
+            for (size_t i = 0; i < n; ++i) {
+                if (grp[i] < 0) continue;
+                for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
+                    uint32_t k = first[grp[i]]++;
+                    L[k].img = (uint32_t)i; L[k].seg0 = sg;
+                }
+            }
+            /* padding descriptors name an image of their own work-group (its tables are staged) */
+            for (uint32_t k = 0; k < total; ++k)
+                if (L[k].seg0 == JD_NO_WAVE) L[k].img = L[k - k % W].img;
+            if (pass) { P->wwg = L; P->n_wwg = total / W; } else { P->hwg = L; P->n_hwg = total / W; }
+        }
+        free(first);
         free(grp); free(cnt);
     }
     free(keys);

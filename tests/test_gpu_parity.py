@@ -546,6 +546,47 @@ def test_extreme_aspect_ratios(pkg, dec, oracle):
         assert np.array_equal(planar.pixels(i), out.pixels(i).transpose(2, 0, 1))
 
 
+def test_batch_large_enough_for_8_wave_write_groups(pkg, dec, oracle):
+    """768 x 1080p (8.5 k waves of segments): the write kernel then runs its 8-wave work-groups
+    (batches whose images use at most four table slots); every image equals the oracle's decode
+    of its stream.  The other GPU tests and tools/soak.py run both variants through
+    JDGPU_WWG_WAVES (see test_write_group_variants_agree)."""
+    files = [pkg.synth.make_jpeg(1920, 1080, seed=70 + i, quality=85, subsamp=1, restart_mcus=(i % 2) * 120) for i in range(6)]
+    descs = pkg.parse_many(files)
+    out = pkg.Batch([descs[i % 6] for i in range(768)]).decode()
+    want = []
+    for f in files:
+        rc, info, q = oracle.qcoef(f)
+        assert rc == 0
+        want.append((q, oracle.to_rgb(oracle.pixels_from_qcoef(info, q))))
+    for i in list(range(12)) + [383, 766, 767]:
+        assert out.status(i) == 0
+        assert np.array_equal(out.qcoef(i).astype(np.int32), want[i % 6][0]), i
+        assert np.array_equal(out.pixels(i), want[i % 6][1]), i
+    assert all(out.status(i) == 0 for i in range(768))
+
+
+def test_write_group_variants_agree(pkg, dec, oracle):
+    """the same mixed batch through the 4-wave and the 8-wave write kernel (forced with
+    JDGPU_WWG_WAVES, read when a batch is created): identical coefficients, pixels and statuses"""
+    files = fuzzed_streams(oracle, count=40) + [pkg.synth.make_jpeg(640, 480, seed=s, quality=90, subsamp=s % 5) for s in range(10)]
+    got = {}
+    for waves in ("4", "8"):
+        os.environ["JDGPU_WWG_WAVES"] = waves
+        try:
+            out = dec.decode(files)
+        finally:
+            del os.environ["JDGPU_WWG_WAVES"]
+        got[waves] = [(out.status(i), out.qcoef(i) if out.status(i) == 0 else None, out.pixels(i) if out.status(i) == 0 else None)
+                      for i in range(len(files))]
+    for a, b in zip(got["4"], got["8"]):
+        assert a[0] == b[0]
+        if a[0] == 0:
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for i in range(len(files) - 10, len(files)):
+        _check_against_oracle(pkg, oracle, dec.decode([files[i]]), 0, files[i])
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
