@@ -1,4 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# 256 images per launch are fewer waves than the plan wants for its 8-wave write groups: take them
+# anyway, so that the counters are those of the kernel the full-size run uses
+export JDGPU_WWG_WAVES=8
 B="python3 bench.py --batch 256 --distinct 16 --steps 2 --warmup 1 --no-cpu-baseline"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d gpurun_out/pmc1 -- $B > gpurun_out/pmc1.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc2 -- $B > gpurun_out/pmc2.log 2>&1 || exit 1
