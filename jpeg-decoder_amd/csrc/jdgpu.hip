@@ -1392,7 +1392,7 @@ struct jdgpu_batch {
     int4 *d_cnt, *d_start_dc, *d_cp_val;
     int2 *d_start_blk;
     int16_t *d_coef;
-    jd_huff_wg *d_hwg, *d_wwg;
+    jd_huff_wg *d_hwg, *d_wwg, *d_rpl;
     jd_pix_wg *d_pwg;
     jd_raw_wg *d_rwg;
     uint2 *d_chunk_cnt, *d_chunk_base;
@@ -1544,7 +1544,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
                     b->d_list_cnt, b->d_status, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
-                    b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg};
+                    b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_rpl, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg};
     for (void *p : bufs) pool_free(p);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -1584,7 +1584,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -1615,6 +1615,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_status, n));
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
+    TRY(dalloc(&b->d_rpl, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
     TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * P.wwg_waves));
@@ -1642,6 +1643,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_rpl, P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
@@ -1707,7 +1709,7 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
         uint32_t *lc = b->d_list_cnt + (size_t)r * P.n;
         hipLaunchKernelGGL(k_chain_check, grid, block, 0, st, b->d_img, b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit,
                            b->d_list, lc);
-        hipLaunchKernelGGL(k_huff_repair, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_hwg,
+        hipLaunchKernelGGL(k_huff_repair, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_rpl,
                            b->d_list, lc, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     }
     return JDGPU_OK;

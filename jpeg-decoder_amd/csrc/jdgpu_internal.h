@@ -185,6 +185,7 @@ typedef struct {
     uint32_t n_segs_cap;     /* total segment capacity */
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
+    jd_huff_wg *rpl;                   /* the hwg waves in the repair kernel's order (n_hwg groups) */
     jd_huff_wg *wwg; uint32_t n_wwg;   /* the same waves in work-groups of wwg_waves (write kernel) */
     uint32_t wwg_waves;
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;

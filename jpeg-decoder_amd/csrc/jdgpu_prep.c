@@ -329,8 +329,17 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         P->wwg_waves = (max_slots <= JD_WWG_SLOTS_BIG && want_big) ? JD_WWG_WAVES_BIG : JD_WG_WAVES;
         uint32_t *first = malloc((n + MAXG + 1) * sizeof *first);
         if (!first) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
-        for (int pass = 0; pass < 2; ++pass) {
-            const uint32_t W = pass ? P->wwg_waves : JD_WG_WAVES;
+        uint32_t max_waves = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (grp[i] >= 0 && (P->img[i].seg_cap + 63u) / 64u > max_waves) max_waves = (P->img[i].seg_cap + 63u) / 64u;
+        /* pass 0: light kernels, pass 1: write kernel, pass 2: repair kernel.  The repair kernel's
+         * waves index an image's repair LIST (entries [seg0, seg0 + 64)); from the second round
+         * on only the first 64 entries of an image exist, so its list is ordered entry block by
+         * entry block across the images of a group: the live waves of a late round then sit
+         * together in few work-groups instead of one per image (a work-group with a single live
+         * wave still holds 17 KB of LDS).  Per 4096 x 1080p sync 7.35 -> 7.15 ms, C4 4.22 -> 3.83 ms. */
+        for (int pass = 0; pass < 3; ++pass) {
+            const uint32_t W = pass == 1 ? P->wwg_waves : JD_WG_WAVES;
             /* first descriptor of every group, work-group aligned */
             uint32_t total = 0;
             for (uint32_t g = 0; g < MAXG + nsolo; ++g) {
@@ -340,17 +349,26 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
             jd_huff_wg *L = malloc((total ? total : 1) * sizeof *L);
             if (!L) { free(first); free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
             for (uint32_t k = 0; k < total; ++k) { L[k].img = 0; L[k].seg0 = JD_NO_WAVE; }
-            for (size_t i = 0; i < n; ++i) {
-                if (grp[i] < 0) continue;
-                for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
-                    uint32_t k = first[grp[i]]++;
-                    L[k].img = (uint32_t)i; L[k].seg0 = sg;
+            if (pass < 2 || all_waves < 8192u) { /* small batches: measured slower entry-block-major (C2 2.19 against 1.87 ms) */
+                for (size_t i = 0; i < n; ++i) {
+                    if (grp[i] < 0) continue;
+                    for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
+                        uint32_t k = first[grp[i]]++;
+                        L[k].img = (uint32_t)i; L[k].seg0 = sg;
+                    }
                 }
+            } else {
+                for (uint32_t e = 0; e < max_waves; ++e)
+                    for (size_t i = 0; i < n; ++i) {
+                        if (grp[i] < 0 || e * 64u >= P->img[i].seg_cap) continue;
+                        uint32_t k = first[grp[i]]++;
+                        L[k].img = (uint32_t)i; L[k].seg0 = e * 64u;
+                    }
             }
             /* padding descriptors name an image of their own work-group (its tables are staged) */
             for (uint32_t k = 0; k < total; ++k)
                 if (L[k].seg0 == JD_NO_WAVE) L[k].img = L[k - k % W].img;
-            if (pass) { P->wwg = L; P->n_wwg = total / W; } else { P->hwg = L; P->n_hwg = total / W; }
+            if (pass == 1) { P->wwg = L; P->n_wwg = total / W; } else if (pass == 0) { P->hwg = L; P->n_hwg = total / W; } else P->rpl = L;
         }
         free(first);
         free(grp); free(cnt);
@@ -455,7 +473,7 @@ long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsig
 }
 
 void jd_plan_free(jd_plan *P) {
-    free(P->img); free(P->luts); if (P->raw_owned) free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg);
+    free(P->img); free(P->luts); if (P->raw_owned) free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg); free(P->rpl);
     free(P->clean); free(P->seg_info);
     memset(P, 0, sizeof *P);
 }
