@@ -17,7 +17,13 @@
  *                              int16 coefficients (src/decoding.c:40-66)
  *   pixel     k_pixel          dequantise, separable fp64 IDCT through LDS, level shift, clamp,
  *                              replicate chroma, YCbCr->RGB, coalesced 12-byte stores
- *                              (src/decoding.c:46,65,68-110, src/image.c:39-51)
+ *                              (src/decoding.c:46,65,68-110, src/image.c:39-51); one
+ *                              instantiation per chroma layout and output layout
+ *
+ * The Huffman kernels take one (image, first segment) descriptor per WAVE; the plan
+ * (jdgpu_prep.c) lets waves of different images share a work-group when the images' flattened
+ * tables are identical.  Host side, at the end of the file: the C ABI, a cache of device buffers
+ * (batches are created while others decode), the pinned staging buffer for uploads.
  */
 #include <hip/hip_runtime.h>
 
