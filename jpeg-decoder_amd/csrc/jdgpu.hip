@@ -453,7 +453,8 @@ __device__ __forceinline__ BitReader make_reader(const uint8_t *clean_img, uint3
     return r;
 }
 
-struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
+struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; uint32_t wide; /* an AC value of 8 or more magnitude bits was met */ };
+#define JD_CNT_WIDE (1 << 30) /* in cp_val[].x and cnt[].x beside the unit count */
 
 /* checkpoints inside a segment: at the first symbol boundary at or after bit (c+1) * JD_CP_BITS
  * a light decode records its state (cp_state) and what it counted since the previous checkpoint
@@ -477,9 +478,10 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
                                                     uint32_t *__restrict__ cp_state, int4 *__restrict__ cp_val,
                                                     uint32_t old_exit) {
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
-    uint32_t bad = 0;
+    uint32_t bad = 0, acs = 0;
     int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;      /* since the last checkpoint */
     int tn = 0, t0 = 0, t1 = 0, t2 = 0;        /* up to the last checkpoint */
+    uint32_t tw = 0;                            /* ... AC sizes met, as `acs` since */
     uint32_t old[JD_CP];
 #pragma unroll
     for (uint32_t c = 0; c < JD_CP; ++c) old[c] = COMPARE ? cp_state[c] : JD_CP_NONE;
@@ -499,6 +501,7 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
             /* DC difference (0 for AC symbols), added to the sum of the unit's component */
             int d = extend_top(top << len, size);
             d = isdc ? d : 0;
+            acs |= isdc ? 0u : size;
             dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
             /* src/decoding.c:53-63: i += run; size 0: run 15 -> skip 16, else end of block */
             k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
@@ -515,20 +518,21 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
         if (c < JD_CP && !matched) {
             if (p >= mark) {
                 const uint32_t st = p | (k << 16) | (b << 24);
-                tn += n; t0 += dc0; t1 += dc1; t2 += dc2;
-                cp_val[c] = make_int4(n, dc0, dc1, dc2); /* also on a match: the way here was new */
+                tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tw |= acs;
+                cp_val[c] = make_int4(n | ((acs & 8u) ? JD_CNT_WIDE : 0), dc0, dc1, dc2); /* also on a match: the way here was new */
                 if (COMPARE && st == old[c]) {
 #pragma unroll
                     for (uint32_t i = c + 1; i <= JD_CP; ++i) {
                         const int4 v = cp_val[i];
-                        tn += v.x; t0 += v.y; t1 += v.z; t2 += v.w;
+                        tn += v.x & (JD_CNT_WIDE - 1); t0 += v.y; t1 += v.z; t2 += v.w;
+                        tw |= (v.x & JD_CNT_WIDE) ? 8u : 0u;
                     }
                     matched = true;
                     p = 0xFFFFFFFFu; /* no further step */
                 } else {
                     cp_state[c] = st;
                 }
-                n = dc0 = dc1 = dc2 = 0;
+                n = dc0 = dc1 = dc2 = 0; acs = 0;
             } else { /* the segment ends before this checkpoint */
                 cp_state[c] = JD_CP_NONE;
                 cp_val[c] = make_int4(0, 0, 0, 0);
@@ -539,12 +543,12 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     if (matched) {
         r.exit_state = old_exit;
     } else {
-        cp_val[JD_CP] = make_int4(n, dc0, dc1, dc2);
-        tn += n; t0 += dc0; t1 += dc1; t2 += dc2;
+        cp_val[JD_CP] = make_int4(n | ((acs & 8u) ? JD_CNT_WIDE : 0), dc0, dc1, dc2);
+        tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tw |= acs;
         const uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
         r.exit_state = JD_ST_PACK(ovs, k, b) | ((bad & 0x2000u) ? JD_ST_BAD : 0u);
     }
-    r.n = tn; r.dc0 = t0; r.dc1 = t1; r.dc2 = t2;
+    r.n = tn; r.dc0 = t0; r.dc1 = t1; r.dc2 = t2; r.wide = (tw >> 3) & 1u;
     return r;
 }
 
@@ -654,7 +658,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
                                               cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
     st_in[gs] = in;
     st_exit[gs] = r.exit_state;
-    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+    /* with the unit count: did the segment hold an AC coefficient of 8 or more magnitude bits
+     * (|value| >= 128)?  Such an image's units do not fit the write kernel's int8 buffers.  Kept
+     * per checkpoint interval, so that a repair that stops at a checkpoint takes the flags of
+     * the part it did not decode again from the decode that did; k_seg_scan gathers them once
+     * the start states are final (a decode from a wrong start state sees garbage symbols). */
+    cnt[gs] = make_int4(r.n | (r.wide ? JD_CNT_WIDE : 0), r.dc0, r.dc1, r.dc2);
 }
 
 __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__restrict__ imgs,
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
                                              st_exit[gs] & ~JD_ST_BAD);
     st_in[gs] = in;
     st_exit[gs] = r.exit_state;
-    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+    cnt[gs] = make_int4(r.n | (r.wide ? JD_CNT_WIDE : 0), r.dc0, r.dc1, r.dc2);
 }
 
 /* ============================================================================================
@@ -750,7 +759,8 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
                                                   const int4 *__restrict__ cnt,
                                                   int2 *__restrict__ start_blk,
                                                   int4 *__restrict__ start_dc,
-                                                  uint32_t *__restrict__ status) {
+                                                  uint32_t *__restrict__ status,
+                                                  uint32_t *__restrict__ wide) {
     __shared__ ScanVal s_wave[4];
     __shared__ ScanVal s_carry;
     const jd_image &im = imgs[blockIdx.x];
@@ -762,12 +772,14 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
         uint32_t seg = base + threadIdx.x;
         bool act = seg < n_segs;
         ScanVal v; v.n = v.d0 = v.d1 = v.d2 = 0; v.f = 0;
-        bool first = false;
+        bool first = false, isw = false;
         if (act) {
             int4 c = cnt[im.seg_off + seg];
             first = (seg_info[im.seg_off + seg] & JD_SEG_FIRST) != 0;
-            v.n = c.x; v.d0 = c.y; v.d1 = c.z; v.d2 = c.w; v.f = first ? 1u : 0u;
+            v.n = c.x & (JD_CNT_WIDE - 1); v.d0 = c.y; v.d1 = c.z; v.d2 = c.w; v.f = first ? 1u : 0u;
+            isw = (c.x & JD_CNT_WIDE) != 0;
         }
+        if (__any(isw) && lane == 0) atomicOr(&wide[blockIdx.x], 1u); /* see k_huff_first */
         ScanVal own = v;
         /* wave-level inclusive scan (Hillis-Steele over 64 lanes) */
 #pragma unroll
@@ -824,7 +836,14 @@ __device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
     return lane * WBUF_BYTES + ((((idx >> 3) + lane) & 7u) << 4) + ((idx & 7u) << 1);
 }
 
-template <uint32_t WAVES, uint32_t SLOTS>
+/* NARROW: 64-byte unit buffers of int8 (24 instead of 16 waves per CU with 8-wave work-groups)
+ * for images none of whose AC coefficients needs more than 7 magnitude bits (the light decodes
+ * tell, `wide`); the DC value travels through the flush queue.  The wide instantiation is
+ * launched beside it and takes the other images; each skips the waves that are not its own. */
+__device__ __forceinline__ uint32_t nbuf_addr(uint32_t lane, uint32_t idx) {
+    return lane * 64u + ((((idx >> 3) + lane) & 7u) << 3) + (idx & 7u);
+}
+template <uint32_t WAVES, uint32_t SLOTS, bool NARROW, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
                                                            const uint8_t *__restrict__ clean,
@@ -835,12 +854,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                                                            const int2 *__restrict__ start_blk,
                                                            const int4 *__restrict__ start_dc,
                                                            int16_t *__restrict__ coef,
-                                                           uint32_t *__restrict__ status) {
+                                                           uint32_t *__restrict__ status,
+                                                           uint32_t *__restrict__ wide) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
     /* <4 waves, 6 table slots>: 51 KB, 3 work-groups = 12 waves per CU; <8, 4> (no image of the
      * batch uses more than 4 slots): 78 KB, 2 work-groups = 16 waves per CU */
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[SLOTS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[64 * WAVES * WBUF_BYTES];
+    constexpr uint32_t UB = NARROW ? 64u : WBUF_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[64 * WAVES * UB];
+    __shared__ int16_t s_qdc[NARROW ? 64 * WAVES : 1]; /* per wave: DC value of the r-th finished unit */
     __shared__ uint32_t s_qblk[64 * WAVES];   /* per wave: global unit index of the r-th finished unit */
     __shared__ uint8_t s_qlane[64 * WAVES];   /* per wave: lane (within the wave) that holds it */
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
@@ -849,7 +871,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const jd_huff_wg wg = wgs[blockIdx.x * WAVES + (threadIdx.x >> 6)]; /* per wave, see k_huff_first */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
-    if (!__syncthreads_or(wg.seg0 < n_segs)) return;
+    /* SPLIT: narrow and wide instantiation run side by side, each on its own images */
+    const bool mine = !SPLIT || ((wide[wg.img] != 0u) != NARROW);
+    if (!__syncthreads_or(wg.seg0 < n_segs && mine)) return;
     const uint32_t lane = threadIdx.x, wlane = lane & 63u, wbase = lane & ~63u;
     const uint32_t seg = wg.seg0 + wlane;
     const jd_lut *const g_lut = luts + im.lut_off;
@@ -859,12 +883,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
-        uint4 *z = reinterpret_cast<uint4 *>(s_buf + lane * WBUF_BYTES);
+        uint4 *z = reinterpret_cast<uint4 *>(s_buf + lane * UB);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) z[q] = make_uint4(0, 0, 0, 0);
+        for (uint32_t q = 0; q < UB / 16u; ++q) z[q] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    bool active = wg.seg0 < n_segs && seg < n_segs;
+    bool active = wg.seg0 < n_segs && seg < n_segs && mine;
     if (!__any(active)) return; /* whole wave beyond the image: no further work-group barrier below */
 
     const uint32_t gs = im.seg_off + (active ? seg : wg.seg0);
@@ -898,6 +922,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), g_lut, s_blk, bpm};
     BlkDesc tb = s_blk[b];
     bool own = (k == 0); /* does this lane own the data unit it is in? */
+    int dcv = 0;         /* NARROW: DC value of the unit in progress */
+    uint32_t ovf = 0;    /* NARROW: an AC value that does not fit (cannot happen when `wide` is complete) */
     int16_t *const cbase = coef + (size_t)im.blk_off * 64;
 
     /* a unit is decoded while it STARTED before the end of the segment */
@@ -924,7 +950,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 const uint32_t kk = isdc ? 0u : k + run;
                 const bool store = isdc || (own && size != 0 && kk < 64u);          /* src/decoding.c:65 */
                 k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : kk + 1u);
-                if (store) *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
+                if (NARROW) {
+                    dcv = isdc ? val : dcv;
+                    ovf |= isdc ? 0u : (uint32_t)(val + 128);
+                    /* a DC step stores a byte of its value at index 0; the flush puts the real one there */
+                    if (store) *reinterpret_cast<int8_t *>(s_buf + nbuf_addr(lane, s_cm[kk & 63u])) = (int8_t)val;
+                } else {
+                    if (store) *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
+                }
                 p += tot;
                 R.advance(tot);
                 if (k >= 64u) {
@@ -943,6 +976,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 uint32_t r = __popcll(fm & ((1ull << wlane) - 1ull));
                 s_qlane[wbase + r] = (uint8_t)wlane;
                 s_qblk[wbase + r] = (uint32_t)fB;
+                if (NARROW) s_qdc[wbase + r] = (int16_t)dcv; /* the unit's DC: dcv is only replaced by the next unit's DC step */
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -951,9 +985,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
             for (uint32_t g = wlane >> 3; g < nf; g += 8) {
                 uint32_t src = wbase + s_qlane[wbase + g];
                 uint32_t blk = s_qblk[wbase + g];
-                uint4 *lp = reinterpret_cast<uint4 *>(s_buf + src * WBUF_BYTES + (((sub + src) & 7u) << 4));
-                uint4 v = *lp;
-                *lp = make_uint4(0, 0, 0, 0);
+                uint4 v;
+                if (NARROW) {
+                    uint2 *lp = reinterpret_cast<uint2 *>(s_buf + src * 64u + (((sub + src) & 7u) << 3));
+                    const uint2 n8 = *lp;
+                    *lp = make_uint2(0, 0);
+                    auto widen = [](uint32_t x, uint32_t sh) { /* bytes sh, sh+1 of x -> two int16 */
+                        return ((uint32_t)(int32_t)(int8_t)(x >> (8 * sh)) & 0xFFFFu) | ((uint32_t)(int32_t)(int8_t)(x >> (8 * sh + 8)) << 16);
+                    };
+                    v = make_uint4(widen(n8.x, 0), widen(n8.x, 2), widen(n8.y, 0), widen(n8.y, 2));
+                    if (sub == 0) v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)s_qdc[wbase + g];
+                } else {
+                    uint4 *lp = reinterpret_cast<uint4 *>(s_buf + src * WBUF_BYTES + (((sub + src) & 7u) << 4));
+                    v = *lp;
+                    *lp = make_uint4(0, 0, 0, 0);
+                }
                 /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
                 uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64 + sub * 8);
                 __builtin_nontemporal_store(v.x, out); __builtin_nontemporal_store(v.y, out + 1);
@@ -967,6 +1013,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     }
     /* data ended before the interval's data units did */
     if (!flags && seg < n_segs && B < limit && is_last) flags |= JDGPU_IMG_EOF;
+    if (NARROW && (ovf & ~255u)) { /* safety net: mark the image wide and have the host run the pass again */
+        atomicOr(&wide[wg.img], 1u);
+        flags |= JDGPU_IMG_UNSYNCED;
+    }
     if (flags) atomicOr(&status[wg.img], flags);
 }
 
@@ -1393,7 +1443,7 @@ struct jdgpu_batch {
     uint8_t *d_raw, *d_clean, *d_pix;
     jd_image *d_img;
     jd_lut *d_luts;
-    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_status, *d_cp_state;
+    uint32_t *d_seg_info, *d_st_in, *d_st_exit, *d_status, *d_cp_state, *d_wide;
     uint32_t *d_list, *d_list_cnt;   /* repair lists: [segment capacity], [JD_REPAIR_ROUNDS][images] */
     int4 *d_cnt, *d_start_dc, *d_cp_val;
     int2 *d_start_blk;
@@ -1549,7 +1599,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
      * still be running (hipFree used to wait for the whole device here) */
     if (b->stream) hipStreamSynchronize(b->stream);
     void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
-                    b->d_list_cnt, b->d_status, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
+                    b->d_list_cnt, b->d_status, b->d_wide, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
                     b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_rpl, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg};
     for (void *p : bufs) pool_free(p);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
@@ -1587,7 +1637,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->flags = flags;
     b->stream = nullptr; b->retries = 0; b->timed = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
-    b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = nullptr;
+    b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
     b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->any_rst = false;
@@ -1619,6 +1669,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_list, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_list_cnt, (size_t)JD_REPAIR_ROUNDS * (n ? n : 1)));
     TRY(dalloc(&b->d_status, n));
+    TRY(dalloc(&b->d_wide, 2 * (n ? n : 1))); /* second half: where a test sends the flags to lose them */
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_rpl, (size_t)P.n_hwg * JD_WG_WAVES));
@@ -1690,16 +1741,30 @@ static void launch_pixel(jdgpu_batch *b, hipStream_t st) {
     if (b->flags & JDGPU_OUT_YCBCR) launch_pixel_formats<true>(b, st); else launch_pixel_formats<false>(b, st);
 }
 
+/* JDGPU_TEST_DROP_WIDE: the scan kernel's flags go nowhere, so that the narrow write kernel meets
+ * values it cannot hold and its safety net (mark the image, run the pass again) is exercised */
+static uint32_t *wide_flags_of(jdgpu_batch *b) {
+    static const bool drop = getenv("JDGPU_TEST_DROP_WIDE") != nullptr;
+    return drop ? b->d_wide + (b->plan.n ? b->plan.n : 1) : b->d_wide;
+}
+
 static void launch_write(jdgpu_batch *b, hipStream_t st) {
     jd_plan &P = b->plan;
-    if (P.wwg_waves == JD_WWG_WAVES_BIG)
-        hipLaunchKernelGGL((k_huff_write<JD_WWG_WAVES_BIG, JD_WWG_SLOTS_BIG>), dim3(P.n_wwg), dim3(64 * JD_WWG_WAVES_BIG), 0, st,
-                           b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk,
-                           b->d_start_dc, b->d_coef, b->d_status);
-    else
-        hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS>), dim3(P.n_wwg), dim3(64 * JD_WG_WAVES), 0, st,
-                           b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk,
-                           b->d_start_dc, b->d_coef, b->d_status);
+#define WRITE_ARGS b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, \
+                   b->d_start_dc, b->d_coef, b->d_status, b->d_wide
+    if (P.wwg_waves == JD_WWG_WAVES_BIG) {
+        static const bool narrow = [] { const char *e = getenv("JDGPU_NARROW"); return !e || atoi(e) != 0; }();
+        const dim3 grid(P.n_wwg), block(64 * JD_WWG_WAVES_BIG);
+        if (narrow) { /* int8 buffers where the image allows, the wide kernel beside it for the rest */
+            hipLaunchKernelGGL((k_huff_write<JD_WWG_WAVES_BIG, JD_WWG_SLOTS_BIG, true, true>), grid, block, 0, st, WRITE_ARGS);
+            hipLaunchKernelGGL((k_huff_write<JD_WWG_WAVES_BIG, JD_WWG_SLOTS_BIG, false, true>), grid, block, 0, st, WRITE_ARGS);
+        } else {
+            hipLaunchKernelGGL((k_huff_write<JD_WWG_WAVES_BIG, JD_WWG_SLOTS_BIG, false, false>), grid, block, 0, st, WRITE_ARGS);
+        }
+    } else {
+        hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, false, false>), dim3(P.n_wwg), dim3(64 * JD_WG_WAVES), 0, st, WRITE_ARGS);
+    }
+#undef WRITE_ARGS
 }
 
 static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
@@ -1729,6 +1794,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     b->retries = 0;
     hipStream_t st = b->stream;
     HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
+    HIPCHK(hipMemsetAsync(b->d_wide, 0, P.n * 4, st)); /* set by the light decodes, kept over repair passes */
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
     if (!(b->flags & JDGPU_HOST_PREP) && P.n_rwg) {
         HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
@@ -1745,7 +1811,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
     if (P.n_hwg) { if (int rc = enqueue_huffman(b, true)) return rc; }
     if (prof) HIPCHK(hipEventRecord(b->ev[2], st));
-    hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
+    hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status, wide_flags_of(b));
     if (prof) HIPCHK(hipEventRecord(b->ev[3], st));
     if (P.n_hwg) launch_write(b, st);
     if (prof) HIPCHK(hipEventRecord(b->ev[4], st));
@@ -1786,7 +1852,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
             for (size_t i = 0; i < P.n; ++i) clean &= lc[i] == 0;
             if (clean) break;
         }
-        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)P.n), dim3(256), 0, s, b->d_img, b->d_seg_info, b->d_cnt, b->d_start_blk, b->d_start_dc, b->d_status, wide_flags_of(b));
         launch_write(b, s);
         launch_pixel(b, s);
         HIPCHK(hipGetLastError());

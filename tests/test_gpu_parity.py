@@ -587,6 +587,49 @@ def test_write_group_variants_agree(pkg, dec, oracle):
         _check_against_oracle(pkg, oracle, dec.decode([files[i]]), 0, files[i])
 
 
+def test_narrow_write_buffers_and_their_safety_net(pkg, oracle):
+    """8-wave write groups keep units in int8 buffers unless the light decodes saw an AC value
+    of 8 or more magnitude bits in the image.  A batch that mixes both kinds decodes right; and
+    with the flags thrown away (JDGPU_TEST_DROP_WIDE, read once per process: a child process) the
+    narrow kernel notices the values it cannot hold, marks the image and the host runs the pass
+    again -- same output, one more pass."""
+    code = """
+import os, sys
+import numpy as np
+sys.path.insert(0, '@ROOT@')
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from oracle.oracle import Oracle
+oracle = Oracle()
+dec = pkg.Decoder(0)
+yy, xx = np.mgrid[0:120, 0:168]
+board = (((xx // 3 + yy // 5) % 2) * 255).astype(np.uint8)       # hard edges: large AC values, orderly streams
+board = np.stack([board, 255 - board, board], -1)
+files = [pkg.synth.encode_rgb(board, quality=98, subsamp=1),
+         pkg.synth.make_jpeg(168, 120, seed=1, quality=60, subsamp=1),
+         pkg.synth.encode_rgb(board[:64, :64], quality=95, subsamp=0, restart_mcus=3),
+         pkg.synth.make_jpeg(640, 480, seed=2, quality=85, subsamp=2)]
+out = dec.decode(files)
+for i, f in enumerate(files):
+    rc, info, q = oracle.qcoef(f)
+    assert rc == 0 and out.status(i) == 0, (i, out.status(i))
+    assert np.array_equal(out.qcoef(i).astype(np.int32), q), i
+    assert np.array_equal(out.pixels(i), oracle.to_rgb(oracle.pixels_from_qcoef(info, q))), i
+assert np.abs(oracle.qcoef(files[0])[2][:, 1:]).max() > 127 and np.abs(oracle.qcoef(files[1])[2][:, 1:]).max() <= 127
+print("retries", out.retries)
+""".replace("@ROOT@", ROOT)
+    retries = {}
+    for mode, extra in (("wide only", {"JDGPU_NARROW": "0"}), ("narrow", {}), ("flags dropped", {"JDGPU_TEST_DROP_WIDE": "1"})):
+        env = dict(os.environ, JDGPU_WWG_WAVES="8", **extra)
+        r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (mode, r.stderr[-2000:])
+        retries[mode] = int(r.stdout.strip().split()[-1])
+    # the noise streams may need repair passes of their own (slow self-synchronisation): the narrow
+    # kernel must not add any while the flags are there, and must add one when they are not
+    assert retries["narrow"] == retries["wide only"], retries
+    assert retries["flags dropped"] > retries["wide only"], retries
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
