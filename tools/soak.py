@@ -13,7 +13,7 @@ from oracle.oracle import Oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 SIDE = int(sys.argv[3]) if len(sys.argv) > 3 else 400
-CHUNK = 256 if SIDE <= 400 else 32
+CHUNK = int(os.environ.get("SOAK_CHUNK", "0")) or (256 if SIDE <= 400 else 32)   # images per batch
 rng = np.random.default_rng(seed)
 oracle = Oracle()
 dec = pkg.Decoder(0)
