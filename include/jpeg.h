@@ -26,25 +26,12 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include "hufftree.h" /* src/jpeg.h:4: huffnode, and with it bitstream */
 #include "image.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-/* src/hufftree.h:10-13 */
-typedef enum HuffTableClass { CLASS_DC = 0, CLASS_AC = 1 } HuffTableClass;
-
-/* src/hufftree.h:15-22: binary code tree, left = 0 bit, right = 1 bit.  The root lives inside
- * jpeg_info; children are heap nodes owned by jpeg_info until jpeg_free. */
-typedef struct huffnode {
-    struct huffnode *left;
-    struct huffnode *right;
-    uint8_t symbol;
-    bool hasLeft;
-    bool hasRight;
-    bool hasSymbol;
-} huffnode;
 
 typedef struct {
     struct jpeg_component_info {

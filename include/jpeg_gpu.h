@@ -68,7 +68,8 @@ enum {
     JDGPU_OUT_RGB = 0,        /* fused YCbCr->RGB store: jpeg_read_image + image_ycbcr_to_rgb */
     JDGPU_OUT_YCBCR = 1,      /* what jpeg_read_image alone leaves in the buffer */
     JDGPU_PROFILE = 2,        /* record HIP events around every stage of each decode */
-    JDGPU_HOST_PREP = 4,      /* debug: unstuff/split the scan on the host instead of on the GPU */
+    /* 4: unused (a debug flag of round 1 that unstuffed on the host; the stage has one
+     * implementation now, on the GPU) */
     /* output layouts other than pixel[] of src/image.h:4-12 (row f3 of SURVEY 8: the 3-byte
      * interleaved layout is what the reference's callers get; loaders want one of these).  Same
      * sample values, rows without padding; combine with JDGPU_OUT_RGB or JDGPU_OUT_YCBCR. */
@@ -91,7 +92,12 @@ enum {
 /* ---- device ---------------------------------------------------------------------------- */
 
 int         jdgpu_device_count(void);
-int         jdgpu_init(int device);          /* bind the calling process to a device; idempotent */
+/* Bind the calling process to a device; idempotent for the same device.  ONE process drives ONE
+ * GPU (images are sharded over processes, one per GPU): the buffer cache, the pinned
+ * staging buffer and the device constants are process-wide, so once a device is bound a call with
+ * another one returns JDGPU_ERR_ARG and changes nothing.  Entry points that need a device and find
+ * none bound bind device 0.  No counterpart in the reference (CPU only). */
+int         jdgpu_init(int device);
 const char *jdgpu_last_error(void);          /* thread-local text of the last failure */
 /* Device buffers of destroyed batches are kept for the next jdgpu_batch_create (allocating and
  * freeing tens of GB per batch would stall a caller that creates one batch while another
@@ -124,7 +130,9 @@ int  jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags,
 /* Enqueue the whole decode (unstuff, sync, scan, write, pixel kernels) on the batch's stream.
  * Inputs are already resident in HBM; may be called repeatedly. */
 int  jdgpu_batch_decode(jdgpu_batch *b);
-/* Wait for the stream; returns JDGPU_OK or the first failure (per-image detail: _status). */
+/* Wait for the stream; returns JDGPU_OK or the first failure (per-image detail: _status).
+ * An image whose status has JDGPU_IMG_EOF or JDGPU_IMG_NOSYMBOL (the reference exits there,
+ * src/macros.h:8) has all-zero pixels; its coefficients are undefined. */
 int  jdgpu_batch_sync(jdgpu_batch *b);
 void jdgpu_batch_destroy(jdgpu_batch *b);
 
@@ -154,22 +162,14 @@ int      jdgpu_batch_retries(const jdgpu_batch *b);
  * the last decode pass (summed over the images); rounds beyond the built-in number read 0 */
 int      jdgpu_batch_repair_counts(jdgpu_batch *b, uint32_t *out, size_t rounds);
 
-/* ---- host-side test hooks: the flattened-table lookup and the unstuff stage as plain C, so the
- *      CPU test-suite can check them against the tree walk (src/hufftree.c:64-78) and the byte
- *      reader (src/bitstream.c:7-18) without a GPU.  Not used by any decode call. ------------ */
-/* decode the code at the top of the 16-bit window v16: 0 ok, -1 no such code, -2 bad table */
-int  jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, unsigned *len,
-                           unsigned *run, unsigned *size);
 /* bytes per bit-segment (one lane decodes one segment) */
 unsigned jdgpu_segment_bytes(void);
-/* returns the number of segments written (each restart interval padded with 0xFF to a whole
- * segment, segments stored one after the other), -1 if the buffers are too small.
- * seg_info[i]: bit 31 = first segment of an interval, low 16 bits = valid bits in the segment. */
-long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
-                        uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap);
 
+/* ---- debug read-back for the tests ------------------------------------------------------------ */
 /* the clean (unstuffed, interval-padded) stream and per-segment words the unstuff stage left on
- * the device for image i; same format as jdgpu_host_unstuff.  Returns the segment count. */
+ * the device for image i: each restart interval padded with 0xFF to a whole segment, segments one
+ * after the other; seg_info[i]: bit 31 = first segment of an interval, low 16 bits = valid bits in
+ * the segment (the format of the tests' host statement, csrc/host_hooks.h).  Returns the segment count. */
 long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t clean_cap,
                                 uint32_t *seg_info, size_t seg_cap);
 

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from . import shard, synth  # noqa: F401  (sharding policy, workload generator)
+from . import shard, synth, workloads  # noqa: F401  (sharding policy, workload generator, named workloads)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JPEGAMD_LIB") or os.path.join(_HERE, "libjpegamd.so")  # override: A/B builds only
@@ -20,7 +20,7 @@ OK = 0
 ERR_HEADER = -1
 ERR_NO_DEVICE = -10
 IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
-OUT_RGB, OUT_YCBCR, PROFILE, HOST_PREP, OUT_4BYTE, OUT_PLANAR = 0, 1, 2, 4, 8, 16
+OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR = 0, 1, 2, 8, 16
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 
 EXPORTS = [
@@ -30,8 +30,7 @@ EXPORTS = [
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_rgb_to_ycbcr",
-    "jdgpu_host_lut_lookup", "jdgpu_host_unstuff", "jdgpu_batch_debug_segments",
-    "jdgpu_segment_bytes",
+    "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
     "image_print", "image_ycbcr_to_rgb", "image_rgb_to_ycbcr",
@@ -112,15 +111,29 @@ def lib():
     L.jdgpu_batch_repair_counts.argtypes = [vp, C.POINTER(C.c_uint32), sz]
     L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_rgb_to_ycbcr.argtypes = [vp, C.c_uint, C.c_uint]
-    L.jdgpu_host_lut_lookup.argtypes = [C.POINTER(HuffSpec), C.c_int, C.c_uint, C.POINTER(C.c_uint),
-                                        C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
-    L.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
-    L.jdgpu_host_unstuff.restype = C.c_long
     L.jdgpu_segment_bytes.restype = C.c_uint
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]
     L.jdgpu_batch_debug_segments.restype = C.c_long
     _lib = L
     return L
+
+
+_hooks = None
+
+
+def hooks():
+    """libjdhooks.so: TEST-ONLY plain-C statements of the table lookup and the unstuff stage
+    (csrc/host_hooks.c); not part of the product library."""
+    global _hooks
+    if _hooks is None:
+        H = C.CDLL(os.path.join(_HERE, "libjdhooks.so"))
+        u8p, sz = C.POINTER(C.c_uint8), C.c_size_t
+        H.jdgpu_host_lut_lookup.argtypes = [C.POINTER(HuffSpec), C.c_int, C.c_uint, C.POINTER(C.c_uint),
+                                            C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        H.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
+        H.jdgpu_host_unstuff.restype = C.c_long
+        _hooks = H
+    return _hooks
 
 
 def _err(L, what, rc):

@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t a
 
 #define SUB_PX 64u                 /* pixels per wave: each wave owns a 64-pixel-wide part of the strip */
 #define PIX_ROW (SUB_PX + 8u)      /* bytes per sample-tile row (+8 spreads the rows over banks) */
-#define PLANE_BYTES (16u * PIX_ROW)
+#define PLANE_BYTES (32u * PIX_ROW) /* generic instantiation: up to 4 units = 32 sample rows per MCU row */
 #define TR_BLK 64u                 /* doubles per 8x8 block in the transpose buffer */
 
 #define WAVE_SYNC()                                                   \
@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                const jd_pix_wg *__restrict__ wgs,
                                                const int16_t *__restrict__ coef,
                                                uint8_t *__restrict__ pix,
+                                               const uint32_t *__restrict__ status,
                                                uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
     /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
@@ -1230,6 +1231,9 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
 
     const jd_pix_wg wg = wgs[blockIdx.x];
+    /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
+     * the data units it never reached hold whatever the (recycled) coefficient buffer held */
+    if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
     const jd_image &im = imgs[wg.img];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     /* one instantiation per pixel layout: the common ones get their geometry as constants */
@@ -1380,7 +1384,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                 }
             } else {
                 /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
-                 * replication shift per component: maxH/H, maxV/V in {1,2} (src/jpeg.c:82) */
+                 * replication shift per component: maxH/H, maxV/V in {1,2,4} (src/jpeg.c:82) */
                 uint32_t hs[3], vs[3], ch[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1408,28 +1412,49 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     }
 }
 
-/* image_ycbcr_to_rgb on a device buffer: src/image.c:39-51, same exact integer form */
-__global__ void k_ycbcr_to_rgb(uint8_t *px, size_t npix) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+/* image_ycbcr_to_rgb on a device buffer: src/image.c:39-51, same exact integer form.  4 pixels =
+ * 12 bytes = three dwords per lane (the buffer is dword aligned); the last lane takes the ragged
+ * rest byte by byte. */
+__global__ __launch_bounds__(256) void k_ycbcr_to_rgb(uint8_t *px, size_t npix) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (i >= npix) return;
-    int Y = px[3 * i], Cb = px[3 * i + 1], Cr = px[3 * i + 2];
-    ChromaTerms ct = chroma_terms(Cb, Cr);
-    px[3 * i] = (uint8_t)clamp255(Y + ct.dr);
-    px[3 * i + 1] = (uint8_t)clamp255(Y + ct.dg - green_fix(ct, Y));
-    px[3 * i + 2] = (uint8_t)clamp255(Y + ct.db);
+    if (i + 4u <= npix) {
+        uint32_t *p = reinterpret_cast<uint32_t *>(px + 3u * i);
+        const uint32_t w[3] = {p[0], p[1], p[2]};
+        uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            auto byte = [&](int j) { return (int)((w[j >> 2] >> (8 * (j & 3))) & 255u); };
+            const int Y = byte(3 * k), Cb = byte(3 * k + 1), Cr = byte(3 * k + 2);
+            const ChromaTerms ct = chroma_terms(Cb, Cr);
+            const uint32_t v[3] = {clamp255(Y + ct.dr), clamp255(Y + ct.dg - green_fix(ct, Y)), clamp255(Y + ct.db)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[(3 * k + c) >> 2] |= v[c] << (8 * ((3 * k + c) & 3));
+        }
+        p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    } else {
+        for (size_t q = i; q < npix; ++q) {
+            int Y = px[3 * q], Cb = px[3 * q + 1], Cr = px[3 * q + 2];
+            ChromaTerms ct = chroma_terms(Cb, Cr);
+            px[3 * q] = (uint8_t)clamp255(Y + ct.dr);
+            px[3 * q + 1] = (uint8_t)clamp255(Y + ct.dg - green_fix(ct, Y));
+            px[3 * q + 2] = (uint8_t)clamp255(Y + ct.db);
+        }
+    }
 }
 
 /* image_rgb_to_ycbcr on a device buffer: src/image.c:54-66 literally -- the same f64 products and
  * sums in the same order (the build disables contraction), clamp, truncating store.  The forward
  * transform has no integer shortcut worth proving: it is off the decode path. */
 __device__ __forceinline__ uint8_t clamp_trunc(double v) { return (uint8_t)(v < 0 ? 0.0 : 255 < v ? 255.0 : v); }
-__global__ void k_rgb_to_ycbcr(uint8_t *px, size_t npix) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
-    const double R = px[3 * i], G = px[3 * i + 1], B = px[3 * i + 2];
-    px[3 * i] = clamp_trunc(0.299 * R + 0.587 * G + 0.114 * B);
-    px[3 * i + 1] = clamp_trunc(-0.1687 * R - 0.3313 * G + 0.5 * B + 128.0);
-    px[3 * i + 2] = clamp_trunc(0.5 * R - 0.4187 * G - 0.0813 * B + 128.0);
+__global__ __launch_bounds__(256) void k_rgb_to_ycbcr(uint8_t *px, size_t npix) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u; /* 4 pixels per lane, as k_ycbcr_to_rgb */
+    for (size_t i = i0; i < npix && i < i0 + 4u; ++i) {
+        const double R = px[3 * i], G = px[3 * i + 1], B = px[3 * i + 2];
+        px[3 * i] = clamp_trunc(0.299 * R + 0.587 * G + 0.114 * B);
+        px[3 * i + 1] = clamp_trunc(-0.1687 * R - 0.3313 * G + 0.5 * B + 128.0);
+        px[3 * i + 2] = clamp_trunc(0.5 * R - 0.4187 * G - 0.0813 * B + 128.0);
+    }
 }
 
 /* ============================================================================================
@@ -1478,6 +1503,14 @@ extern "C" int jdgpu_init(int device) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         snprintf(g_err, sizeof g_err, "no HIP device visible: the MI355X backend has no CPU fallback");
         return JDGPU_ERR_NO_DEVICE;
+    }
+    /* One process drives one GPU (images are sharded over processes).  The buffer
+     * cache, the pinned staging buffer, the constant tables are
+     * process-wide and belong to the device bound first: binding another one is refused rather
+     * than handing device-A buffers to a device-B batch. */
+    if (g_device >= 0 && device != g_device) {
+        snprintf(g_err, sizeof g_err, "this process is bound to device %d: jdgpu_init(%d) refused (one process per GPU)", g_device, device);
+        return JDGPU_ERR_ARG;
     }
     if (device < 0 || device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (0..%d)", device, n - 1); return JDGPU_ERR_ARG; }
     HIPCHK(hipSetDevice(device));
@@ -1689,11 +1722,6 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
         P.raw = g_stage; P.raw_owned = 0;
         jd_plan_gather(&P, descs, n);
         if (trace) { fprintf(stderr, "[jdgpu] gather %.1f ms\n", now() - t0); t0 = now(); }
-        if (b->flags & JDGPU_HOST_PREP) {
-            jd_plan_unstuff_host(&P);
-            HIPTRY(hipMemcpy(b->d_clean, P.clean, P.clean_bytes, hipMemcpyHostToDevice));
-            HIPTRY(hipMemcpy(b->d_seg_info, P.seg_info, (size_t)P.n_segs_cap * 4, hipMemcpyHostToDevice));
-        }
         HIPTRY(hipMemcpy(b->d_raw, P.raw, P.raw_bytes, hipMemcpyHostToDevice));
         P.raw = nullptr;
     }
@@ -1710,7 +1738,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemsetAsync(b->d_status, 0, (n ? n : 1) * 4, b->stream));
     if (trace) { HIPTRY(hipStreamSynchronize(b->stream)); fprintf(stderr, "[jdgpu] output clear %.1f ms\n", now() - t0); }
     /* the host copies of the bulky arrays are not needed any more */
-    free(P.clean); P.clean = nullptr; free(P.luts); P.luts = nullptr;
+    free(P.luts); P.luts = nullptr;
     *out = b;
     return JDGPU_OK;
 }
@@ -1720,7 +1748,7 @@ static void launch_pixel_mode(jdgpu_batch *b, hipStream_t st) {
     const uint32_t *f = b->plan.pwg_mode_first;
     if (f[MODE + 1] > f[MODE])
         hipLaunchKernelGGL((k_pixel<OUT_YCBCR, MODE, FMT>), dim3(f[MODE + 1] - f[MODE]), dim3(64 * JD_PIX_WAVES), 0, st,
-                           b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->plan.pix_rows);
+                           b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->d_status, b->plan.pix_rows);
 }
 template <bool OUT_YCBCR, uint32_t FMT>
 static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
@@ -1802,7 +1830,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
     HIPCHK(hipMemsetAsync(b->d_wide, 0, P.n * 4, st)); /* set by the light decodes, kept over repair passes */
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
-    if (!(b->flags & JDGPU_HOST_PREP) && P.n_rwg) {
+    if (P.n_rwg) {
         HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
         hipLaunchKernelGGL(k_unstuff_count, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_cnt);
         hipLaunchKernelGGL(k_unstuff_chunks, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u);
@@ -1959,7 +1987,7 @@ static int convert_host_pixels(void (*kernel)(uint8_t *, size_t), const char *wh
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), npix * 3));
     hipError_t e = hipMemcpy(d, host_pixels, npix * 3, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, 0, d, npix);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((npix + 1023) / 1024)), dim3(256), 0, 0, d, npix);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost);

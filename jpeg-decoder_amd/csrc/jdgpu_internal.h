@@ -194,18 +194,14 @@ typedef struct {
     uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;
     uint32_t px_bytes;     /* output bytes per pixel: 3, or 4 with JDGPU_OUT_4BYTE */
-    /* filled only by jd_prep_unstuff_host (JDGPU_HOST_PREP) */
-    uint8_t *clean;          /* [clean_bytes] */
-    uint32_t *seg_info;      /* [n_segs_cap] */
 } jd_plan;
 
 int  jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd_plan *plan, char *err, size_t errlen);
 void jd_plan_gather(jd_plan *plan, const jdgpu_image_desc *descs, size_t n); /* copies the scans into plan->raw (threads) */
-void jd_plan_unstuff_host(jd_plan *plan);
 void jd_plan_free(jd_plan *plan);
 int  jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut);
 uint32_t jd_unstuff_image(const uint8_t *src, size_t raw_len, int use_rst, uint32_t n_intervals,
-                          uint8_t *dst, uint32_t *seg_info);
+                          uint8_t *dst, uint32_t *seg_info); /* host_hooks.c (libjdhooks.so, tests only) */
 
 extern const uint8_t jd_zigzag_to_cm[64];   /* zigzag k -> col*8+row */
 

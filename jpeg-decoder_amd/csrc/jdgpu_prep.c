@@ -7,10 +7,9 @@
  * tables re-ordered for the pixel kernel, the concatenated scan bytes and the work-group
  * descriptors of the Huffman and pixel kernels.
  *
- * jd_plan_unstuff_host() is the host statement of the unstuff stage (src/bitstream.c:7-18
- * plus restart-marker splitting).  The product runs that stage on the GPU (k_unstuff_* in
- * jdgpu.hip); this one exists for JDGPU_HOST_PREP debugging and as the structure the GPU
- * stage is checked against.
+ * The unstuff stage (src/bitstream.c:7-18 plus restart-marker splitting) runs on the GPU
+ * (k_unstuff_* in jdgpu.hip).  Its plain-C statement, which the tests check the GPU stage
+ * against, is test infrastructure and lives in host_hooks.c / libjdhooks.so, outside this library.
  */
 #include "jdgpu_internal.h"
 
@@ -179,17 +178,22 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         int ok = (d->ncomp == 3 || d->ncomp == 1) && d->width && d->height && d->scan_len < 0xFFFFFF00u;
         if (d->ncomp == 1 && (d->comp[0].H != 1 || d->comp[0].V != 1)) ok = 0; /* src/jpeg.c:80-81 would walk
                                                                                   H x V units per "MCU" */
-        unsigned seen = 0, maxH = 0, maxV = 0;
+        unsigned seen = 0, maxH = 0, maxV = 0, units = 0;
         for (unsigned c = 0; ok && c < nc; ++c) {
+            units += (unsigned)d->comp[c].H * d->comp[c].V;
             unsigned id = d->comp[c].id;
             if (id < 1 || id > 3 || (seen >> id & 1)) ok = 0; /* channel = id-1, SURVEY 8(c) */
             seen |= 1u << id;
-            if (d->comp[c].H < 1 || d->comp[c].H > 2 || d->comp[c].V < 1 || d->comp[c].V > 2) ok = 0;
+            /* factors 1, 2 and 4 (4:1:1, 4:1:0): the replication ratios maxH/H, maxV/V are then powers
+             * of two, as the pixel kernel's shifts need; the reference takes 1..4 (src/parsing.c:42-46) */
+            if ((d->comp[c].H != 1 && d->comp[c].H != 2 && d->comp[c].H != 4) ||
+                (d->comp[c].V != 1 && d->comp[c].V != 2 && d->comp[c].V != 4)) ok = 0;
             if (d->comp[c].Tq > 3 || d->comp[c].Td > 3 || d->comp[c].Ta > 3) ok = 0;
             if (ok && (!d->huff_defined[0][d->comp[c].Td] || !d->huff_defined[1][d->comp[c].Ta])) ok = 0;
             if (d->comp[c].H > maxH) maxH = d->comp[c].H;
             if (d->comp[c].V > maxV) maxV = d->comp[c].V;
         }
+        if (units > JD_MAX_BPM) ok = 0; /* 4x4 luma + chroma: 18 data units per MCU, beyond the state word's unit field */
         im->width = d->width; im->height = d->height;
         im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
         im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
@@ -392,88 +396,9 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
     return JDGPU_OK;
 }
 
-/* ---- host statement of the unstuff stage --------------------------------------------------------
- * Reference semantics (src/bitstream.c:11-14): a 0xFF that is read as data stays in the stream
- * and the byte after it is dropped whatever its value.  Restart extension: with a restart
- * interval, 0xFF 0xD0..0xD7 is a marker -- both bytes go, and the next interval starts. */
-uint32_t jd_unstuff_image(const uint8_t *src, size_t raw_len, int use_rst, uint32_t n_intervals,
-                          uint8_t *dst, uint32_t *si) {
-    uint32_t seg = 0, ivl = 0;
-    size_t o = 0, ivl_start = 0, p = 0; /* o: write offset in dst */
-    for (;;) {
-        int at_end = p >= raw_len;
-        int marker = !at_end && use_rst && src[p] == 0xFF && p + 1 < raw_len &&
-                     src[p + 1] >= 0xD0 && src[p + 1] <= 0xD7;
-        /* a marker beyond the last interval the frame geometry allows ends the data: nothing
-         * after it can belong to the scan (the decoder stops at the next marker, T.81 E.2.4) */
-        if (marker && ivl + 1 >= n_intervals) at_end = 1;
-        if (at_end || marker) {
-            /* close the interval: pad to a segment boundary, emit its segment words */
-            size_t len = o - ivl_start;
-            uint32_t ns = (uint32_t)((len + JD_SEG_BYTES - 1) / JD_SEG_BYTES);
-            if (ns == 0) ns = 1;
-            for (uint32_t s = 0; s < ns; ++s) {
-                size_t bits = len * 8 > (size_t)s * JD_SEG_BITS ? len * 8 - (size_t)s * JD_SEG_BITS : 0;
-                si[seg + s] = (uint32_t)(bits > JD_SEG_BITS ? JD_SEG_BITS : bits) | (s == 0 ? JD_SEG_FIRST : 0);
-            }
-            seg += ns;
-            for (size_t q = o; q < ivl_start + (size_t)ns * JD_SEG_BYTES; ++q) dst[q] = 0xFF;
-            o = ivl_start + (size_t)ns * JD_SEG_BYTES;
-            ivl_start = o;
-            ++ivl;
-            if (at_end) break;
-            p += 2;
-            continue;
-        }
-        uint8_t c = src[p++];
-        dst[o++] = c;
-        if (c == 0xFF) ++p; /* drop the follower */
-    }
-    return seg;
-}
-
-void jd_plan_unstuff_host(jd_plan *P) {
-    free(P->clean); free(P->seg_info);
-    P->clean = malloc(P->clean_bytes);
-    P->seg_info = calloc(P->n_segs_cap ? P->n_segs_cap : 1, sizeof *P->seg_info);
-    memset(P->clean, 0xFF, P->clean_bytes);
-    for (size_t i = 0; i < P->n; ++i) {
-        jd_image *im = &P->img[i];
-        if (!im->ncomp) continue;
-        /* unstuff linearly, then store in the device layout: 64-segment groups, word-transposed */
-        uint8_t *lin = malloc((size_t)im->seg_cap * JD_SEG_BYTES);
-        im->n_segs = jd_unstuff_image(P->raw + im->raw_off, im->raw_len, im->ri_blocks != 0, im->n_intervals,
-                                      lin, P->seg_info + im->seg_off);
-        uint8_t *dst = P->clean + im->clean_off;
-        for (uint32_t s = 0; s < im->n_segs; ++s)
-            for (uint32_t o = 0; o < JD_SEG_BYTES; ++o)
-                dst[(((size_t)(s >> 6) * (JD_SEG_BYTES / 16u) + (o >> 4)) * 64u + (s & 63u)) * 16u + (o & 15u)] = lin[(size_t)s * JD_SEG_BYTES + o];
-        free(lin);
-    }
-}
-
-/* ---- host test hooks (declared in include/jpeg_gpu.h) ----------------------------------------- */
-
-int jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16, unsigned *len,
-                          unsigned *run, unsigned *size) {
-    jd_lut lut;
-    if (jd_lut_build(spec, is_dc, &lut)) return -2;
-    jd_sym s = jd_lut_lookup(&lut.hot, &lut, v16 & 0xFFFFu);
-    *len = s.len; *run = s.run; *size = s.size;
-    return s.bad ? -1 : 0;
-}
-
 unsigned jdgpu_segment_bytes(void) { return JD_SEG_BYTES; }
-
-long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
-                        uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap) {
-    size_t need = (len + JD_SEG_BYTES - 1) / JD_SEG_BYTES + (n_intervals ? n_intervals : 1);
-    if (seg_cap < need || clean_cap < need * JD_SEG_BYTES) return -1;
-    return (long)jd_unstuff_image(scan, len, (int)use_rst, n_intervals ? n_intervals : 1, clean, seg_info);
-}
 
 void jd_plan_free(jd_plan *P) {
     free(P->img); free(P->luts); if (P->raw_owned) free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg); free(P->rpl);
-    free(P->clean); free(P->seg_info);
     memset(P, 0, sizeof *P);
 }

@@ -92,6 +92,14 @@ static size_t tree_from_dht(huffnode *root, const uint8_t *payload) {
     return (size_t)(sym - payload);
 }
 
+/* src/hufftree.h:24-25, reachable through the reference's jpeg.h:4: the tree builder and its
+ * release.  Host-side header work, as in the reference; the decode never walks the tree. */
+size_t hufftree_parse(huffnode *buf, const unsigned char *data) {
+    memset(buf, 0, sizeof *buf); /* src/hufftree.c:44: *buf may be uninitialised, never read it */
+    return tree_from_dht(buf, data);
+}
+void hufftree_destroy(huffnode *tree) { node_free_children(tree); }
+
 /* in-order walk: leaves in increasing code order -> counts per depth + symbols (a DHT payload) */
 static void tree_flatten(const huffnode *n, unsigned depth, jdgpu_huff_spec *spec, unsigned *nsym) {
     if (depth && n->hasSymbol) {
@@ -127,6 +135,13 @@ static int seg_huffman(jpeg_info *ji, const uint8_t *d, unsigned n) {
     for (size_t at = 0; at < n;) {
         unsigned cls = d[at] >> 4, id = d[at] & 15u;
         if (cls > 1 || id > 3) return -1;
+        /* the 16 counts and the symbols they announce must lie inside the segment.  The
+         * reference does not check (src/parsing.c:61-78, src/hufftree.c:53 read on into whatever
+         * its 64 KiB buffer held before); a table cut off by the segment end is rejected here. */
+        if (at + 17 > n) return -1;
+        size_t total = 0;
+        for (unsigned l = 0; l < 16; ++l) total += d[at + 1 + l];
+        if (at + 17 + total > n) return -1;
         at += 1 + tree_from_dht(&ji->huffmanTables[cls][id], d + at + 1);
     }
     return 0;
@@ -170,7 +185,15 @@ static int read_header(jpeg_info *ji, scan_info *si, source *s) {
     memset(si, 0, sizeof *si);
     if (src_word(s) != M_SOI || s->failed) return -1;
     for (;;) {
-        unsigned marker = src_word(s), length = src_word(s);
+        unsigned marker = src_word(s);
+        /* extension: T.81 B.1.1.2 allows any number of 0xFF fill bytes in front
+         * of a marker, and TEM / RSTn stand alone, without a length.  The reference reads
+         * marker + length unconditionally (src/jpeg.c:32-37) and takes the bytes that follow as
+         * a length.  Every other marker word goes the reference's way. */
+        while (marker == 0xFFFFu && !s->failed) marker = 0xFF00u | ((unsigned)src_byte(s) & 0xFFu);
+        if (s->failed) return -1;
+        if (marker == 0xFF01u || (marker >= 0xFFD0u && marker <= 0xFFD7u)) continue;
+        unsigned length = src_word(s);
         if (length < 2) return -1;
         unsigned n = length - 2;
         if (src_read(s, payload, n) != n) return -1;
@@ -309,7 +332,7 @@ void jpeg_read_image(pixel *img, const jpeg_info *info, const scan_info *scanInf
     if (!rc) rc = jdgpu_batch_sync(b);
     if (rc) die(jdgpu_last_error());
     uint32_t st = jdgpu_batch_status(b, 0);
-    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components or 1, ids 1..3, sampling factors 1 or 2).");
+    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components or 1, ids 1..3, sampling factors 1, 2 or 4, at most 12 data units per MCU).");
     if (st & JDGPU_IMG_NOSYMBOL) die("Could not find next symbol in huffnode."); /* src/hufftree.c:69,72 */
     if (st & JDGPU_IMG_EOF) die("Reached end of file.");                         /* src/bitstream.c:17 */
     if (jdgpu_batch_read_pixels(b, 0, img)) die(jdgpu_last_error());

@@ -34,7 +34,7 @@ EXAMPLES = ["birb.jpg", "pineapple.jpg", "no_subsampling/ferris_wheel.jpg",
             "no_subsampling/lake.jpg", "no_subsampling/pineapple.jpg",
             "no_subsampling/skyline.jpg"]
 
-# (name, w, h, seed, quality, subsamp(0=444,1=420,2=422,3=440), restart_mcus)
+# (name, w, h, seed, quality, subsamp(0=444,1=420,2=422,3=440, 5..8 below), restart_mcus)
 SYNTH = [
     ("syn_64x48_420_q85", 64, 48, 1, 85, 1, 0),
     ("syn_64x48_444_q85", 64, 48, 2, 85, 0, 0),
@@ -47,6 +47,13 @@ SYNTH = [
     ("syn_96x40_422_q80", 96, 40, 9, 80, 2, 0),
     ("syn_72x96_440_q75", 72, 96, 10, 75, 3, 0),
     ("syn_320x240_422_q90", 320, 240, 11, 90, 2, 0),
+    # sampling factor 4 (the reference accepts 1..4, src/parsing.c:42-46): 5 = luma 4x1 (4:1:1),
+    # 6 = luma 4x2 (4:1:0), 7 = luma 1x4, 8 = luma 2x4; sizes multiples of the replication
+    ("syn_64x48_411_q85", 64, 48, 12, 85, 5, 0),
+    ("syn_160x64_410_q80", 160, 64, 13, 80, 6, 0),
+    ("syn_48x64_v4_q85", 48, 64, 14, 85, 7, 0),
+    ("syn_104x72_411_q70", 104, 72, 15, 70, 5, 0),
+    ("syn_80x96_2x4_q90", 80, 96, 16, 90, 8, 0),
 ]
 # DRI twins of non-DRI streams: (name, base name, restart_mcus)
 SYNTH_DRI = [

@@ -128,10 +128,21 @@ int ojpeg_parse(const uint8_t *f, size_t len, ojpeg_info *info) {
     p = 2;
     unsigned marker;
     do { /* src/jpeg.c:32-55 */
-        if (p + 4 > len) return OJPEG_ERR_HEADER;
+        if (p + 2 > len) return OJPEG_ERR_HEADER;
         marker = (unsigned)be16(f + p);
-        unsigned seglen = (unsigned)be16(f + p + 2);
-        p += 4;
+        p += 2;
+        /* EXTENSION (like DRI below; the reference has neither): 0xFF fill bytes in front of a
+         * marker and the length-less markers TEM / RSTn (T.81 B.1.1.2, B.1.1.3).  The reference
+         * takes the two bytes after ANY marker word as a length (src/jpeg.c:32-37); only the
+         * marker words 0xFFFF, 0xFF01 and 0xFFD0..0xFFD7 are treated differently here. */
+        while (marker == 0xFFFF) {
+            if (p >= len) return OJPEG_ERR_HEADER;
+            marker = 0xFF00u | f[p++];
+        }
+        if (marker == 0xFF01 || (marker >= 0xFFD0 && marker <= 0xFFD7)) continue;
+        if (p + 2 > len) return OJPEG_ERR_HEADER;
+        unsigned seglen = (unsigned)be16(f + p);
+        p += 2;
         if (seglen < 2) return OJPEG_ERR_HEADER;
         unsigned dl = seglen - 2;
         if (p + dl > len) return OJPEG_ERR_HEADER; /* short fread, src/jpeg.c:41 */

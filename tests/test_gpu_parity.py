@@ -664,7 +664,7 @@ def test_stage_timers(pkg, dec):
 
 def _host_unstuff(pkg, scan, use_rst, n_intervals):
     import ctypes as C
-    L = pkg.lib()
+    L = pkg.hooks()
     SB = pkg.segment_bytes()
     cap = len(scan) // SB + n_intervals + 2
     clean = np.zeros(cap * SB, np.uint8)
@@ -720,10 +720,126 @@ def test_unstuff_stage_equals_host_statement(pkg, dec, oracle):
         assert np.array_equal(got_clean, want_clean), i
 
 
-def test_host_prep_flag_gives_identical_output(pkg, dec):
-    files = [golden_stream(n) for n in all_golden_names()]
-    a = dec.decode(files)
-    h = dec.decode(files, flags=pkg.HOST_PREP)
-    for i in range(len(files)):
-        assert a.status(i) == h.status(i) == 0
-        assert np.array_equal(a.qcoef(i), h.qcoef(i)) and np.array_equal(a.rgb(i), h.rgb(i))
+def test_factor_four_layouts_vs_oracle(pkg, dec, oracle):
+    """sampling factor 4 (4:1:1, 4:1:0, luma 1x4 and 2x4; the reference takes 1..4,
+    src/parsing.c:42-46, and its own output on five such streams is in tests/golden): ragged
+    sizes, restart markers, every output layout, next to ordinary streams in one batch"""
+    files = []
+    for ss in (5, 6, 7, 8):
+        mw = {5: 32, 6: 32, 7: 8, 8: 16}[ss]
+        for (w, h) in ((64, 64), (200, 136), (36, 20), (1, 1), (33, 65), (640, 480)):
+            mcux = -(-w // mw)
+            for ri in (0, mcux):
+                files.append(pkg.synth.make_jpeg(w, h, seed=ss * 1000 + w, quality=75 + ss, subsamp=ss, restart_mcus=ri))
+        files.append(pkg.synth.make_jpeg(64, 48, seed=ss, quality=85, subsamp=1))
+    out = dec.decode(files)
+    for i, f in enumerate(files):
+        _check_against_oracle(pkg, oracle, out, i, f)
+    planar = dec.decode(files, pkg.OUT_PLANAR | pkg.OUT_YCBCR)
+    for i in range(0, len(files), 5):
+        rc, want = oracle.ycbcr(files[i])
+        assert rc == 0 and np.array_equal(planar.pixels(i), want.transpose(2, 0, 1))
+    # 4x4 luma + chroma = 18 data units per MCU: reported, not decoded
+    d = pkg.parse(files[0])
+    d.comp[0].V = 4
+    assert pkg.Batch([d]).decode().status(0) == pkg.IMG_UNSUPPORTED
+
+
+def test_fill_bytes_stream_equals_its_twin(pkg, dec, manifest):
+    """SURVEY 8 row f2, last item: 0xFF fill bytes and stand-alone markers in the header (fixture
+    tests/golden/streams_ext/fill_bytes_420.jpg, built by test_host_boundary.with_fill_bytes):
+    decodes to what the reference made of the plain stream"""
+    f = open(os.path.join(ROOT, "tests", "golden", "streams_ext", "fill_bytes_420.jpg"), "rb").read()
+    out = dec.decode([f, golden_stream("syn_64x48_420_q85")])
+    assert out.status(0) == 0 and out.status(1) == 0
+    assert np.array_equal(out.qcoef(0), out.qcoef(1))
+    assert hashlib.md5(out.rgb(0).tobytes()).hexdigest() == manifest["syn_64x48_420_q85"]["md5_rgb"]
+
+
+def test_failed_images_have_zero_pixels(pkg, dec, oracle):
+    """an image whose entropy decode stops (EOF / no symbol) used to be rendered from
+    whatever the recycled coefficient buffer held.  Its pixels are zero now, on fresh and on
+    recycled buffers, in every layout; its neighbours are untouched"""
+    good = pkg.synth.make_jpeg(264, 200, seed=9, quality=90, subsamp=1)
+    off = oracle.parse(good)[1].scan_offset
+    cut = good[:off + (len(good) - off) // 2]
+    for flags in (pkg.OUT_RGB, pkg.OUT_YCBCR | pkg.OUT_PLANAR, pkg.OUT_4BYTE):
+        a = dec.decode([good] * 3, flags)        # fills the buffers the next batch inherits
+        want = a.pixels(0).copy()
+        a.close()
+        b = dec.decode([good, cut, good], flags)
+        assert b.status(1) & pkg.IMG_EOF
+        assert not b.pixels(1).any()
+        assert np.array_equal(b.pixels(0), want) and np.array_equal(b.pixels(2), want)
+        b.decode()                                # the same resident batch again
+        assert not b.pixels(1).any()
+        b.close()
+
+
+def test_one_process_one_device(pkg, dec):
+    """jdgpu_init: idempotent for the bound device, refuses another one (process-wide buffer cache,
+    staging buffer and constants belong to the first) -- checked before the range check, so the
+    refusal shows on a one-GPU box too"""
+    L = pkg.lib()
+    assert L.jdgpu_init(0) == 0
+    assert L.jdgpu_init(0) == 0
+    rc = L.jdgpu_init(1)
+    assert rc == -12 and b"bound to device 0" in L.jdgpu_last_error()
+    assert L.jdgpu_init(-1) == -12
+    out = dec.decode([golden_stream("syn_8x8_444_q85")])    # still bound and working
+    assert out.status(0) == 0
+
+
+def test_config2_examples_x1024(pkg, dec, manifest):
+    """BASELINE config 2: the four examples/no_subsampling files, 1024 images in one interleaved
+    batch -- every image byte-identical to the reference's output (md5 of tests/golden)"""
+    files = pkg.workloads.c2_files()
+    descs = pkg.parse_many(files)
+    out = pkg.Batch([descs[i % 4] for i in range(1024)]).decode()
+    want = [manifest[n]["md5_rgb"] for n in pkg.workloads.C2_NAMES]
+    assert all(out.status(i) == 0 for i in range(1024))
+    for i in list(range(16)) + list(range(500, 516)) + list(range(1008, 1024)):
+        assert hashlib.md5(out.rgb(i).tobytes()).hexdigest() == want[i % 4], i
+    ref_q = [out.qcoef(i) for i in range(4)]
+    for i in range(4, 1024, 37):
+        assert np.array_equal(out.qcoef(i), ref_q[i % 4]), i
+
+
+def test_config5_per_gpu_shard(pkg, dec, oracle):
+    """BASELINE config 5, the part one GPU gets: the global list of 65536 mixed-size 4:2:0 / 4:4:4
+    images (pkg.workloads, exactly what bench.py --workload c5 builds), rank 3 of 8 by
+    shard_greedy, decoded as ONE batch.  All statuses 0; every distinct stream (all sizes x both
+    layouts, 96 of them) checked against the oracle -- coefficients bit-exact, RGB identical -- on the
+    first batch image that carries it, and a seeded sample of 160 further images against those."""
+    wl = pkg.workloads
+    params = wl.c5_params(96)
+    files = wl.encode_all(params)
+    descs = pkg.parse_many(files)
+    world, rank = 8, 3
+    mine, total = wl.c5_shard(descs, world, rank)
+    assert total == 65536 and 7000 < len(mine) < 9400
+    # the eight shards partition the global list, and their costs balance
+    cost = [pkg.shard.image_cost(d.scan_len, d.width * d.height) for d in descs]
+    sizes, loads = [], []
+    for r in range(world):
+        m, _ = wl.c5_shard(descs, world, r)
+        sizes.append(len(m))
+        loads.append(sum(cost[i] for i in m))
+    assert sum(sizes) == total and max(loads) - min(loads) <= max(cost)
+    kinds = {(params[i][0], params[i][1], params[i][4]) for i in mine}
+    assert len(kinds) == 12                                  # 6 sizes x 2 layouts
+    out = pkg.Batch([descs[i] for i in mine]).decode()
+    assert all(out.status(k) == 0 for k in range(out.n))
+    assert out.retries == 0
+    first = {}
+    for k, i in enumerate(mine):
+        first.setdefault(i, k)
+    assert len(first) == 96
+    ref = {}
+    for i, k in first.items():
+        _check_against_oracle(pkg, oracle, out, k, files[i])
+        ref[i] = (out.qcoef(k), out.rgb(k))
+    rng = np.random.default_rng(5)
+    for k in rng.choice(out.n, 160, replace=False):
+        q, rgb = ref[mine[int(k)]]
+        assert np.array_equal(out.qcoef(int(k)), q) and np.array_equal(out.rgb(int(k)), rgb), int(k)

@@ -178,7 +178,7 @@ def _canonical_decode(counts, symbols, v16):
 def test_flattened_tables_equal_tree_walk(pkg):
     """every 16-bit window of every distinct table in the fixtures: the flattened lookup the
     kernels use == the bitwise code walk (test pyramid item 1)"""
-    L = pkg.lib()
+    L = pkg.hooks()
     seen = {}
     for name in all_golden_names():
         d = pkg.parse(golden_stream(name))
@@ -240,7 +240,7 @@ def test_two_level_tables_random_codes(pkg, seed):
         spec.counts[i] = counts[i]
     for i, sy in enumerate(syms):
         spec.symbols[i] = int(sy)
-    L = pkg.lib()
+    L = pkg.hooks()
     ln, run, size = C.c_uint(), C.c_uint(), C.c_uint()
     for v in range(65536):
         rc = L.jdgpu_host_lut_lookup(C.byref(spec), 0, v, C.byref(ln), C.byref(run), C.byref(size))
@@ -262,7 +262,7 @@ def _ref_reader_bytes(scan):
 
 
 def _unstuff(pkg, scan, use_rst=0, n_intervals=1):
-    L = pkg.lib()
+    L = pkg.hooks()
     SB = pkg.segment_bytes()
     cap = len(scan) // SB + n_intervals + 2
     clean = np.zeros(cap * SB, np.uint8)
@@ -436,3 +436,136 @@ def test_cli_messages():
     assert r.returncode == 1 and r.stdout.startswith("Could not open file: ")   # src/test.c:17
     r = subprocess.run([exe, os.path.join(ROOT, "BASELINE.json")], capture_output=True, text=True)
     assert r.returncode == 1 and r.stdout == "Could not parse file.\n"          # src/test.c:24
+
+
+def _insert_before(data, marker, extra):
+    i = data.index(marker)
+    return data[:i] + extra + data[i:]
+
+
+def with_fill_bytes(data):
+    """the same stream with 0xFF fill bytes in front of several markers and two stand-alone
+    markers (TEM, RST3) between segments: legal per T.81 B.1.1.2, unreadable for the reference
+    (src/jpeg.c:32-37 takes the bytes after any marker word as a length)"""
+    out = _insert_before(data, b"\xff\xdb", b"\xff")                 # one fill byte before DQT
+    out = _insert_before(out, b"\xff\xc0", b"\xff\xff\xff")          # three before SOF0
+    out = _insert_before(out, b"\xff\xc4", b"\xff\x01")              # TEM, no length
+    out = _insert_before(out, b"\xff\xda", b"\xff\xd3\xff\xff")      # RST3 + two fill bytes before SOS
+    return out
+
+
+def test_fill_bytes_and_standalone_markers(pkg, oracle):
+    """SURVEY 8 row f2, last item: fill bytes / length-less markers in the header loop.  Same
+    descriptor as the plain stream; the oracle's twin extension agrees (scan offset moved by the
+    inserted bytes); the committed fixture is this construction"""
+    for name in ("syn_64x48_420_q85", "ex_no_subsampling_lake", "syn_64x48_420_q85_dri4"):
+        plain = golden_stream(name)
+        filled = with_fill_bytes(plain)
+        assert len(filled) == len(plain) + 10
+        a, b = pkg.parse(plain), pkg.parse(filled)
+        size = C.sizeof(pkg.ImageDesc)
+        assert C.string_at(C.addressof(a), size)[8:] == C.string_at(C.addressof(b), size)[8:]
+        assert C.string_at(b.scan, 16) == C.string_at(a.scan, 16)
+        rc, info = oracle.parse(filled)
+        assert rc == 0 and info.scan_offset == oracle.parse(plain)[1].scan_offset + 10
+        rc1, rgb1 = oracle.rgb(plain)
+        rc2, rgb2 = oracle.rgb(filled)
+        assert rc1 == 0 and rc2 == 0 and np.array_equal(rgb1, rgb2)
+    fixture = open(os.path.join(ROOT, "tests", "golden", "streams_ext", "fill_bytes_420.jpg"), "rb").read()
+    assert fixture == with_fill_bytes(golden_stream("syn_64x48_420_q85"))
+    # fill bytes that run into the end of the file, and a marker word that is not one, still fail
+    with pytest.raises(pkg.JpegError):
+        pkg.parse(golden_stream("syn_8x8_444_q85")[:20] + b"\xff" * 9)
+    assert oracle.parse(golden_stream("syn_8x8_444_q85")[:20] + b"\xff" * 9)[0] == -1
+
+
+def test_truncated_dht_is_rejected(pkg):
+    """a DHT table header near the end of its segment used to make the 16 counts and
+    the symbols be read from beyond the segment (up to ~4 KB past the 64 KiB payload buffer for a
+    segment of length 0xFFFF).  The counts and the symbols they announce must fit the segment."""
+    good = golden_stream("syn_8x8_444_q85")
+    k = good.index(b"\xff\xc4")
+    ln = int.from_bytes(good[k + 2:k + 4], "big")
+    table = good[k + 4:k + 2 + ln]                       # class/id byte + 16 counts + symbols
+    # a maximal segment: the first table, then filler tables, then a table header in its last byte
+    body = bytearray(table)
+    filler = bytes([0x00]) + bytes(16)                   # an empty DC table 0: 17 bytes, no symbols
+    while len(body) + len(filler) <= 0xFFFF - 2 - 1:
+        body += filler
+    body += b"\x00" * (0xFFFF - 2 - 1 - len(body)) if len(body) < 0xFFFF - 3 else b""
+    assert pkg.parse(good)                                # sanity
+    for tail in (b"\x10", b"\x10" + bytes([1] * 10)):    # header only / counts cut short
+        seg = bytes(body[:0xFFFF - 2 - len(tail)]) + tail
+        assert len(seg) == 0xFFFF - 2
+        bad = good[:k] + b"\xff\xc4\xff\xff" + seg + good[k + 2 + ln:]
+        with pytest.raises(pkg.JpegError):
+            pkg.parse(bad)
+    # counts that announce more symbols than the segment holds
+    b = bytearray(good)
+    b[k + 5 + 15] = 200                                   # 200 codes of length 16 that are not there
+    with pytest.raises(pkg.JpegError):
+        pkg.parse(bytes(b))
+
+
+def test_reference_types_and_tree_functions(pkg, tmp_path):
+    """what the reference's jpeg.h:4 drags in (src/hufftree.h:10-27, src/bitstream.h:7-17): the
+    types compile, hufftree_parse / hufftree_destroy are exported and build the reference's tree;
+    the serial decode primitives are declared but deliberately NOT exported (no CPU decode path)"""
+    prog = tmp_path / "tree.c"
+    prog.write_text(r'''
+#include "jpeg.h"
+#include <string.h>
+int main(void) {
+    bitstream bs; memset(&bs, 0, sizeof bs); bs._bitsLeft = 3; bs._c = 0xA5; bs._fp = NULL;   /* the type is visible */
+    huffnode root;                                  /* uninitialised, as a caller of the reference may pass it */
+    unsigned char dht[16 + 3] = {0, 1, 2};          /* one code of length 2, two of length 3 */
+    dht[16] = 7; dht[17] = 8; dht[18] = 9;
+    size_t used = hufftree_parse(&root, dht);
+    /* codes: 00 -> 7, 010 -> 8, 011 -> 9 */
+    int ok = used == 19 && root.hasLeft && !root.hasRight && root.left->hasLeft && root.left->left->hasSymbol &&
+             root.left->left->symbol == 7 && root.left->right->left->symbol == 8 && root.left->right->right->symbol == 9;
+    hufftree_destroy(&root);
+    printf("%d %zu %d\n", ok, sizeof(bitstream), (int)CLASS_AC);
+    return ok ? 0 : 1;
+}
+''')
+    exe = tmp_path / "tree"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", INC, str(prog), "-L", libdir, "-ljpegamd",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "16", "1"]
+    syms = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in ("hufftree_parse", "hufftree_destroy"):
+        assert f" T {name}" in syms
+    for name in ("bitstream_create", "bitstream_get_bit", "bitstream_get_bits", "hufftree_decode_next_symbol",
+                 "jdgpu_host_unstuff", "jdgpu_host_lut_lookup"):
+        assert name not in syms, f"{name}: a CPU decode primitive / test hook inside the product library"
+
+
+def test_reference_cli_source_builds_unchanged_against_include(pkg, tmp_path):
+    """drop-in check: the reference's own src/test.c, unmodified and read where it lies, compiles
+    against include/ and links against libjpegamd.so (this container only: the GPU box has no
+    /root/reference).  On a box without a GPU the program then fails loudly."""
+    src = "/root/reference/src/test.c"
+    if not os.path.exists(src):
+        pytest.skip("/root/reference is not present")
+    exe = tmp_path / "reftest_on_amd"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I", INC, src, "-L", libdir, "-ljpegamd",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout == "No path given.\n"
+    if not _have_gpu(pkg):
+        r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "streams", "ex_birb.jpg")], capture_output=True)
+        assert r.returncode != 0 and b"no HIP device" in r.stderr
+
+
+def test_factor_four_layouts_are_planned(pkg):
+    """ADVICE r1: the reference accepts sampling factors 1..4 (src/parsing.c:42-46); 4:1:1 and its
+    relatives parse, and the descriptor carries the factors (decode parity: the GPU suite, against
+    the reference's own output in tests/golden)"""
+    for name, hv in (("syn_64x48_411_q85", (4, 1)), ("syn_160x64_410_q80", (4, 2)), ("syn_48x64_v4_q85", (1, 4)),
+                     ("syn_80x96_2x4_q90", (2, 4))):
+        d = pkg.parse(golden_stream(name))
+        assert (d.comp[0].H, d.comp[0].V) == hv and (d.comp[1].H, d.comp[1].V) == (1, 1)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 import bench
-files = bench.make_files(pkg, "c3", 64, 0)
+files = bench.make_files(pkg, "c3", 64)
 dec = pkg.Decoder(0)
 descs = [pkg.parse(f) for f in files]
 for parts in (1, 2, 4):

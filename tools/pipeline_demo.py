@@ -12,7 +12,7 @@ import bench
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 P = min(2, int(sys.argv[2]) if len(sys.argv) > 2 else 2)   # each batch in flight holds ~56 GB of HBM at 4096 x 1080p
 BS = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-files = bench.make_files(pkg, "c3", 64, 0)
+files = bench.make_files(pkg, "c3", 64)
 dec = pkg.Decoder(0)
 batch_files = [files[i % 64] for i in range(BS)]
 q = queue.Queue(maxsize=2)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: randomized parity soak on the GPU box.  N random streams (sizes 1..400, all five
-layouts, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
+layouts plus the four with a sampling factor of 4, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
 decoded in batches of 256 in every output layout, each compared with the oracle: status class,
 coefficients and pixels bit for bit.  usage: soak.py [N] [seed] [max_side, default 400]"""
 import os, sys, time
@@ -24,10 +24,12 @@ t0 = time.time()
 while done < N:
     files = []
     for _ in range(min(CHUNK, N - done)):
-        ss = int(rng.integers(0, 5))
+        ss = int(rng.integers(0, 9))
         w, h = int(rng.integers(1, SIDE + 1)), int(rng.integers(1, SIDE + 1))
         q = int(rng.integers(1, 101))
-        mcus = -(-w // (16 if ss in (1, 2) else 8)) * -(-h // (16 if ss in (1, 3) else 8))
+        mw = {1: 16, 2: 16, 5: 32, 6: 32, 8: 16}.get(ss, 8)
+        mh = {1: 16, 3: 16, 6: 16, 7: 32, 8: 32}.get(ss, 8)
+        mcus = -(-w // mw) * -(-h // mh)
         ri = 0 if rng.random() < 0.5 else int(rng.integers(1, mcus + 2))
         kind = rng.random()
         if kind < 0.7:

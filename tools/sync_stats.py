@@ -6,7 +6,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-files = bench.make_files(pkg, wl, 16, 0)
+files = bench.make_files(pkg, wl, 16)
 dec = pkg.Decoder(0)
 use = [files[i % len(files)] for i in range(256)]
 b = dec.batch(use)
