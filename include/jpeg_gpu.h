@@ -175,6 +175,17 @@ long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t
 
 /* ---- image.h on the device: src/image.c:39-51 over a host buffer (H2D, kernel, D2H) ------ */
 int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height);
+/* The same without any allocation.  NO COUNTERPART IN THE REFERENCE: it is for callers that cannot
+ * allocate device memory where they call -- tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not stall on the allocator.  jdgpu_ycbcr_to_rgb stages the pixels in
+ * a device buffer it allocates and frees per call; this variant stages them in a static device
+ * array of 32 MiB that the library holds on its GPU from load to process end, so it calls no
+ * hipMalloc / hipFree (nor any other allocating routine).  Limit: width * height * 3 <= 32 MiB
+ * (11 184 810 pixels; 3840 x 2160 fits), larger inputs return JDGPU_ERR_ARG and leave the buffer
+ * untouched.  All calls of a process share the one array: they are serialised by a lock inside
+ * the library (concurrent callers wait, they do not race); the array keeps the previous call's
+ * bytes, which never matter -- a call reads only what it has just uploaded. */
+int jdgpu_ycbcr_to_rgb_noalloc(void *host_pixels, unsigned width, unsigned height);
 /* src/image.c:54-66 the same way (row f4 of SURVEY 8; off the decode path: image_rgb_to_ycbcr of
  * include/image.h stays host C, this is for callers whose pixels are large) */
 int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height);

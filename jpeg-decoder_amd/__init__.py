@@ -29,7 +29,7 @@ EXPORTS = [
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
-    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_rgb_to_ycbcr",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_rgb_to_ycbcr",
     "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
@@ -110,6 +110,7 @@ def lib():
     L.jdgpu_batch_retries.argtypes = [vp]
     L.jdgpu_batch_repair_counts.argtypes = [vp, C.POINTER(C.c_uint32), sz]
     L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
+    L.jdgpu_ycbcr_to_rgb_noalloc.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_rgb_to_ycbcr.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_segment_bytes.restype = C.c_uint
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]

@@ -1489,6 +1489,15 @@ struct jdgpu_batch {
 static std::mutex g_mu;
 static int g_device = -1;
 
+/* Scratch for jdgpu_ycbcr_to_rgb_noalloc: device staging memory that exists from module load to
+ * process end, so that entry point never allocates.  g_scratch is its device address on the
+ * bound device (hipGetSymbolAddress in jdgpu_init); host code never uses the array's name for
+ * anything else.  One call at a time uses it (g_scratch_mu). */
+#define JD_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) uint8_t scratch[JD_SCRATCH_BYTES];
+static uint8_t *g_scratch = nullptr;
+static std::mutex g_scratch_mu;
+
 extern "C" const char *jdgpu_last_error(void) { return g_err; }
 
 extern "C" int jdgpu_device_count(void) {
@@ -1505,7 +1514,7 @@ extern "C" int jdgpu_init(int device) {
         return JDGPU_ERR_NO_DEVICE;
     }
     /* One process drives one GPU (images are sharded over processes).  The buffer
-     * cache, the pinned staging buffer, the constant tables are
+     * cache, the pinned staging buffer, the constant tables and the static scratch array are
      * process-wide and belong to the device bound first: binding another one is refused rather
      * than handing device-A buffers to a device-B batch. */
     if (g_device >= 0 && device != g_device) {
@@ -1516,6 +1525,10 @@ extern "C" int jdgpu_init(int device) {
     HIPCHK(hipSetDevice(device));
     if (g_device != device) {
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_zz_cm), jd_zigzag_to_cm, 64));
+        /* the device address of the static scratch array: its name is a host-side stand-in */
+        void *sp = nullptr;
+        HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+        g_scratch = static_cast<uint8_t *>(sp);
         g_device = device;
     }
     return JDGPU_OK;
@@ -1993,6 +2006,30 @@ static int convert_host_pixels(void (*kernel)(uint8_t *, size_t), const char *wh
     if (e == hipSuccess) e = hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost);
     hipFree(d);
     if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e)); return JDGPU_ERR_HIP; }
+    return JDGPU_OK;
+}
+
+/* jdgpu_ycbcr_to_rgb without any allocation: the staging memory is the static scratch array */
+extern "C" int jdgpu_ycbcr_to_rgb_noalloc(void *host_pixels, unsigned width, unsigned height) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const size_t npix = (size_t)width * height;
+    if (!npix) return JDGPU_OK;
+    if (!host_pixels) { snprintf(g_err, sizeof g_err, "jdgpu_ycbcr_to_rgb_noalloc: null buffer"); return JDGPU_ERR_ARG; }
+    if (npix * 3 > JD_SCRATCH_BYTES) {
+        snprintf(g_err, sizeof g_err, "jdgpu_ycbcr_to_rgb_noalloc: %u x %u pixels need %zu bytes, the static scratch holds %u (%u pixels)",
+                 width, height, npix * 3, JD_SCRATCH_BYTES, JD_SCRATCH_BYTES / 3u);
+        return JDGPU_ERR_ARG;
+    }
+    if (!g_scratch) { snprintf(g_err, sizeof g_err, "jdgpu_ycbcr_to_rgb_noalloc: no scratch address (jdgpu_init failed?)"); return JDGPU_ERR_HIP; }
+    /* the array is shared by every call of the process: one at a time.  Nothing has to start at
+     * zero -- the kernel reads and writes exactly the 3 * npix bytes uploaded here. */
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    uint8_t *d = g_scratch;
+    HIPCHK(hipMemcpy(d, host_pixels, npix * 3, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ycbcr_to_rgb, dim3((unsigned)((npix + 1023) / 1024)), dim3(256), 0, 0, d, npix);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost));
     return JDGPU_OK;
 }
 
