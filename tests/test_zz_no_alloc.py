@@ -20,7 +20,8 @@ def test_noalloc_colour_conversion_equals_the_allocating_entry_point():
     for (w, h) in ((1920, 1080), (200, 137), (3, 1), (0, 5), (4096, 2730)):
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         if w * h:
-            img.reshape(-1, 3)[:4] = [(128, 28, 228), (94, 28, 228), (165, 28, 228), (255, 0, 255)]  # the exceptional chroma pair
+            special = np.array([(128, 28, 228), (94, 28, 228), (165, 28, 228), (255, 0, 255)], np.uint8)  # the exceptional chroma pair
+            img.reshape(-1, 3)[:min(4, w * h)] = special[:min(4, w * h)]
         want = img.copy()
         assert L.jdgpu_ycbcr_to_rgb(want.ctypes.data, w, h) == 0
         got = img.copy()
