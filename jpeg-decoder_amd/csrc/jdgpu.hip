@@ -338,34 +338,79 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
  * Huffman: per-lane sequential decoder over one segment of the clean stream
  * ========================================================================================== */
 
-/* per data unit of the MCU, in LDS: everything the decode loops need when a unit starts */
+/*
+ * Lookup tables in LDS.  The host flattens every Huffman table into jd_lut_hot (jdgpu_prep.c:
+ * 10-bit primary + exact sub-tables, entries = code length, magnitude size, zero run).  When a
+ * work-group stages the tables it rewrites the resolved entries into the form its decode loop
+ * wants, so that a symbol step needs no case distinction between DC, AC, ZRL and EOB:
+ *
+ *   kinc = how far the symbol moves the zigzag index k (src/decoding.c:50-66: i += run, then the
+ *          loop's ++i): DC 1 (k: 0 -> 1), AC run + 1, ZRL 16, any other (r, 0) 64 -- "end of block"
+ *          is simply k >= 64, which also ends a unit whose last coefficient sits at index 63.
+ *
+ *   light entry (k_huff_first / k_huff_repair; AC magnitudes are skipped, not read):
+ *     4:0 bits consumed (code + magnitude), 11:5 kinc, 12 an AC magnitude of 8 bits or more,
+ *     13 no such code; in a DC table 11:8 = magnitude size instead (kinc is 1, and the DC
+ *     difference is read: the segment's sums of differences are what k_seg_scan turns into the
+ *     DC predictors at every segment start)
+ *   write entry (k_huff_write):
+ *     3:0 code length - 1, 7:4 magnitude size, 14:8 kinc (0 = no such code)
+ *
+ * Link entries (bit 15, see jd_lut_hot) stay as they are.
+ */
+#define LE_WIDE 0x1000u
+#define LE_BAD  0x2000u
+
+__device__ __forceinline__ uint32_t kinc_of(uint32_t size, uint32_t run, bool is_dc) {
+    const uint32_t zero = run == 15u ? 16u : 64u;  /* ZRL skips 16, any other (r, 0) ends the block */
+    const uint32_t ac = size ? run + 1u : zero;
+    return is_dc ? 1u : ac;
+}
+/* hot entry (or the fields of a jd_sym) -> light / write entry */
+__device__ __forceinline__ uint32_t light_entry(uint32_t len, uint32_t size, uint32_t run, bool bad, bool is_dc) {
+    const uint32_t mid = is_dc ? (1u << 5) | (size << 8) : kinc_of(size, run, false) << 5;
+    return (len + size) | mid | ((!is_dc && size >= 8u) ? LE_WIDE : 0u) | (bad ? LE_BAD : 0u);
+}
+__device__ __forceinline__ uint32_t write_entry(uint32_t len, uint32_t size, uint32_t run, bool bad, bool is_dc) {
+    return ((len - 1u) & 15u) | (size << 4) | (bad ? 0u : kinc_of(size, run, is_dc) << 8);
+}
+template <bool LIGHT>
+__device__ __forceinline__ uint32_t convert_entry(uint32_t e, bool is_dc) {
+    if (e & JD_LUT_LINK) return e;
+    const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
+    const bool bad = (e & 0x2000u) != 0;
+    return LIGHT ? light_entry(len, size, run, bad, is_dc) : write_entry(len, size, run, bad, is_dc);
+}
+
+/* per data unit of the MCU, in LDS: byte offsets of the unit's DC / AC table in the LDS copy,
+ * slots = dc slot | ac slot << 4 (canonical fallback only), nb = the unit after it in the MCU;
+ * e0..e2 select the unit's component: 1 / 0 (light decodes, multiplied) or -1 / 0 (k_huff_write,
+ * used as masks) */
 struct __attribute__((aligned(16))) BlkDesc {
-    uint32_t dc_off, ac_off;   /* byte offsets of the unit's DC / AC lookup tables in the LDS copy */
-    uint32_t slots;            /* dc slot | ac slot << 4 (canonical fallback only) */
+    uint32_t dc_off, ac_off, slots, nb;
+    int e0, e1, e2;
     uint32_t pad;
-    int e0, e1, e2;            /* selects the unit's component: 1 / 0 (light decodes, multiplied) or
-                                  -1 / 0 (k_huff_write, used as masks) */
-    uint32_t pad2;
 };
 
 struct SegTables {
-    const uint8_t *lut;     /* LDS copy of the lookup part of the image's JD_LUT_SLOTS tables */
+    const uint8_t *lut;     /* LDS copy of the lookup part of the image's tables, converted */
     const jd_lut *glut;     /* the whole tables in global memory (canonical fallback) */
     const BlkDesc *blk;     /* LDS */
     uint32_t bpm;
 };
 
-typedef jd_sym SymInfo;
-
-/* one symbol lookup against the LDS tables; `off` = byte offset of the table.  Returns the
- * resolved entry (format of jd_lut_hot::primary). */
-__device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, uint32_t off, uint32_t slot_sel, uint32_t top) {
+/* one symbol lookup against the LDS tables: desc = the unit's BlkDesc, isdc selects its DC or AC
+ * table.  Returns the resolved (light or write) entry. */
+template <bool LIGHT>
+__device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top) {
+    const uint32_t off = isdc ? desc.dc_off : desc.ac_off;
     uint32_t e = *reinterpret_cast<const uint16_t *>(T.lut + off + ((top >> (32 - JD_LUT_BITS)) << 1));
-    if (__builtin_expect((e & JD_LUT_LINK) != 0, 0)) {
+    if (__builtin_expect(e >= JD_LUT_LINK, 0)) {
         const uint32_t first = e & 0xFFFu;
         if (__builtin_expect(first == JD_LUT_NOSUB, 0)) {
-            jd_sym s = jd_lut_lookup_canon(T.glut + slot_sel, top >> 16);
-            e = s.len | (s.size << 5) | (s.run << 9) | (s.bad ? 0x2000u : 0u);
+            const uint32_t slot = isdc ? (desc.slots & 15u) : (desc.slots >> 4);
+            const jd_sym s = jd_lut_lookup_canon(T.glut + slot, top >> 16);
+            e = LIGHT ? light_entry(s.len, s.size, s.run, s.bad != 0, isdc) : write_entry(s.len, s.size, s.run, s.bad != 0, isdc);
         } else {
             const uint32_t rest = (top >> 16) & ((1u << (16 - JD_LUT_BITS)) - 1u);
             const uint32_t idx = first + (rest >> ((16 - JD_LUT_BITS) - ((e >> 12) & 7u)));
@@ -377,6 +422,15 @@ __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, uint32_t of
 
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; } /* v_mad_i32_i24 */
 
+/* JPEG EXTEND (src/decoding.c:31-33) of the `size` magnitude bits that END at bit 32 - tot of the
+ * 32-bit window `top` (i.e. the last `size` of the first `tot` bits); size 0 -> 0.  A magnitude
+ * below 2^(size-1) stands for mag - (2^size - 1): with m = 2^size - 1 that is 2 mag < m. */
+__device__ __forceinline__ int extend_at(uint32_t top, uint32_t tot, uint32_t size) {
+    const uint32_t mag = __builtin_amdgcn_ubfe(top, 32u - tot, size);
+    const uint32_t m = (1u << size) - 1u;
+    return (int)mag - (int)(mag + mag < m ? m : 0u);
+}
+
 /* magnitude bits -> value (JPEG EXTEND, src/decoding.c:31-33); v = stream bits left aligned at
  * the first magnitude bit; size 0 -> 0 whatever v holds */
 __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
@@ -385,75 +439,81 @@ __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
     return (int)mag + (((int)v < 0) ? 0 : neg);
 }
 
-/* JPEG EXTEND (src/decoding.c:31-33), size 0 -> 0 */
-__device__ __forceinline__ int extend(uint32_t bits, uint32_t size) {
-    return (size == 0) ? 0 : ((bits >> (size - 1)) ? (int)bits : (int)bits - (int)(1u << size) + 1);
-}
-
 /*
  * MSB-first bit reader over the lane's segment (and the first words of the next one: a symbol
- * may straddle the boundary), replacing src/bitstream.c:28-45.  64-bit window, refilled one
- * 32-bit word at a time from a three-deep register prefetch queue so that the global loads
- * (L2 / Infinity Cache latency) are never on the symbol-to-symbol critical path.
+ * may straddle the boundary), replacing src/bitstream.c:28-45.  The decode loops take
+ * JD_RSTEPS = 2 symbols per iteration; the reader is built around that:
+ *
+ *   window  three 32-bit words.  The next 32 stream bits are the low r bits of w0 followed by
+ *           the high 32 - r bits of w1 -- one v_alignbit_b32.  Consuming bits decrements r; when
+ *           w0 is used up the window shifts by a word (two selects), which two symbols of at
+ *           most 31 bits can do twice: w2 is what the second shift moves in.
+ *   refill  once per iteration, for all lanes, outside any divergent code: the words the shifts
+ *           used up come from (qa, qb), which were loaded at the END OF THE PREVIOUS iteration,
+ *           and (qa, qb) are loaded again.  So no load is ever waited for right after its issue
+ *           (the compiler places the wait at the first use), the L2 / Infinity Cache latency has
+ *           a whole iteration to pass, and there is no refill branch that some lane of the wave
+ *           takes in every step anyway.
  */
+#ifndef JD_RSTEPS
+#define JD_RSTEPS 2
+#endif
 struct BitReader {
-    const uint32_t *base;      /* the image's clean stream (uniform) */
+    const char *base;          /* the image's clean stream (uniform: a scalar base + 32-bit lane offsets; the plan keeps a
+                                  stream below 4 GiB) */
     uint32_t own, dnx;         /* dword index of word 0 of this segment; distance to that of the next */
-    uint64_t buf;              /* next bits, left aligned */
-    uint32_t cnt;              /* valid bits in buf (>= 33 between symbols) */
-    uint32_t q1, q2;           /* the next two words (raw, big-endian) */
-    uint32_t ql, wl;           /* the word after those and its index; (re)loaded every step */
+    uint32_t w0, w1, w2;       /* window (byte-swapped to native order) */
+    int r;                     /* unread bits of w0, 0..31 */
+    uint32_t s;                /* window shifts since the last refill, 0..2 */
+    uint32_t qa, qb;           /* the two words behind the window (raw, big-endian) */
+    uint32_t c;                /* index of the word in qa */
 
     /* raw (big-endian) word w of this segment, w >= JD_SEG_WORDS: of the next; the byte swap is
      * done when the word is USED, so that the load stays in flight instead of being waited for */
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
-        uint32_t o = ((w & (JD_SEG_WORDS - 4u)) << 6) | (w & 3u);     /* 16-byte pieces are 256 dwords apart */
-        return base[own + o + (w >= JD_SEG_WORDS ? dnx : 0u)];
+        const uint32_t o = ((w & (JD_SEG_WORDS - 4u)) << 6) | (w & 3u);     /* 16-byte pieces are 256 dwords apart */
+        return *reinterpret_cast<const uint32_t *>(base + ((own + o + (w >= JD_SEG_WORDS ? dnx : 0u)) << 2));
     }
+    /* start at bit p of the segment */
     __device__ __forceinline__ void init(uint32_t p) {
-        uint32_t w = p >> 5;
-        uint32_t w0 = word(w), w1 = word(w + 1);
-        q1 = word(w + 2); q2 = word(w + 3); wl = w + 4; ql = word(wl);
-        buf = (((uint64_t)__builtin_bswap32(w0) << 32) | __builtin_bswap32(w1)) << (p & 31u);
-        cnt = 64u - (p & 31u);
+        const uint32_t W = (p + 31u) >> 5;          /* word that holds w1; w0 = the one before (unused when p % 32 == 0) */
+        w0 = __builtin_bswap32(word(W ? W - 1u : 0u));
+        w1 = __builtin_bswap32(word(W));
+        w2 = __builtin_bswap32(word(W + 1u));
+        r = (int)((32u - (p & 31u)) & 31u);
+        s = 0;
+        c = W + 2u; qa = word(c); qb = word(c + 1u);
     }
-    __device__ __forceinline__ uint32_t top() const { return (uint32_t)(buf >> 32); }
-    /* drop n <= 31 bits; branch-free refill from the register queue */
-    __device__ __forceinline__ void advance(uint32_t n) {
-        buf <<= n;
-        cnt -= n;
-        const bool need = cnt <= 32u;
-        uint64_t ins = (uint64_t)__builtin_bswap32(q1) << ((32u - cnt) & 31u);
-        buf |= need ? ins : 0ull;
-        cnt += need ? 32u : 0u;
-        q1 = need ? q2 : q1;
-        q2 = need ? ql : q2;      /* ql was loaded a step ago: its latency is off the critical path */
-        wl += need ? 1u : 0u;
-    }
-    /* unconditional (re)load of the queue tail: no divergent merge ever touches a load that is
-     * still in flight, so the only wait is one whole step after the issue */
-    __device__ __forceinline__ void prefetch() { ql = word(wl); }
-    /* refill and reload only when a word was used up */
+    __device__ __forceinline__ uint32_t top() const { return __builtin_amdgcn_alignbit(w0, w1, (uint32_t)r); }
+    /* drop n <= 31 bits; at most JD_RSTEPS calls between two refills */
     __device__ __forceinline__ void consume(uint32_t n) {
-        buf <<= n;
-        cnt -= n;
-        if (cnt <= 32u) {
-            buf |= (uint64_t)__builtin_bswap32(q1) << (32u - cnt);
-            cnt += 32u;
-            q1 = q2; q2 = ql; ++wl; ql = word(wl);
-        }
+        r -= (int)n;
+        const bool need = r < 0;
+        w0 = need ? w1 : w0;
+        w1 = need ? w2 : w1;
+        r += need ? 32 : 0;
+        s += need ? 1u : 0u;
+    }
+    __device__ __forceinline__ void refill() {
+        const uint32_t a = __builtin_bswap32(qa), b = __builtin_bswap32(qb);
+        w1 = s == 2u ? a : w1;                     /* two shifts left w1 = w2 = the old w2 */
+        w2 = s == 2u ? b : (s == 1u ? a : w2);
+        c += s; s = 0;
+        qa = word(c); qb = word(c + 1u);
     }
 };
 
 __device__ __forceinline__ BitReader make_reader(const uint8_t *clean_img, uint32_t seg, uint32_t n_segs) {
     BitReader r;
-    r.base = reinterpret_cast<const uint32_t *>(clean_img);
+    r.base = reinterpret_cast<const char *>(clean_img);
     r.own = (uint32_t)clean_word_index(seg, 0);
     r.dnx = (seg + 1 < n_segs) ? (uint32_t)clean_word_index(seg + 1, 0) - r.own : 0u;
     return r;
 }
 
-struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; uint32_t wide; /* an AC value of 8 or more magnitude bits was met */ };
+/* what a light decode reports: the exit state, n = data units COMPLETED | JD_CNT_WIDE when an AC
+ * value of 8 or more magnitude bits was met, and the sums of the DC differences per component */
+struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
 #define JD_CNT_WIDE (1 << 30) /* in cp_val[].x and cnt[].x beside the unit count */
 
 /* checkpoints inside a segment: at the first symbol boundary at or after bit (c+1) * JD_CP_BITS
@@ -478,10 +538,10 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
                                                     uint32_t *__restrict__ cp_state, int4 *__restrict__ cp_val,
                                                     uint32_t old_exit) {
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
-    uint32_t bad = 0, acs = 0;
-    int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;      /* since the last checkpoint */
-    int tn = 0, t0 = 0, t1 = 0, t2 = 0;        /* up to the last checkpoint */
-    uint32_t tw = 0;                            /* ... AC sizes met, as `acs` since */
+    uint32_t fl = 0;             /* OR of the entries since the last checkpoint: LE_WIDE, LE_BAD */
+    int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;  /* units completed, DC difference sums since the last checkpoint */
+    int tn = 0, t0 = 0, t1 = 0, t2 = 0;    /* ... up to the last checkpoint */
+    uint32_t tf = 0;
     uint32_t old[JD_CP];
 #pragma unroll
     for (uint32_t c = 0; c < JD_CP; ++c) old[c] = COMPARE ? cp_state[c] : JD_CP_NONE;
@@ -493,46 +553,48 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
         const uint32_t mark = (c + 1u) * JD_CP_BITS;
         const uint32_t lim = c < JD_CP ? min(valid, mark) : valid;
         while (p < lim) {
-            const uint32_t top = R.top();
-            const bool isdc = (k == 0);
-            const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
-            const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
-            bad |= e;
-            /* DC difference (0 for AC symbols), added to the sum of the unit's component */
-            int d = extend_top(top << len, size);
-            d = isdc ? d : 0;
-            acs |= isdc ? 0u : size;
-            dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
-            /* src/decoding.c:53-63: i += run; size 0: run 15 -> skip 16, else end of block */
-            k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
-            const uint32_t tot = len + size;
-            p += tot;
-            R.consume(tot); /* measured against advance() + prefetch() here: 6.2 vs 6.8 ms per 2048 images */
-            /* end of the data unit, branch-free; the descriptor is re-read in every step so that
-             * no divergent merge copies it around */
-            const bool end = k >= 64u;
-            const uint32_t nb = (b + 1 == T.bpm) ? 0 : b + 1;
-            k = end ? 0u : k; n += end ? 1 : 0; b = end ? nb : b;
-            tb = T.blk[b];
+#pragma unroll
+            for (int st = 0; st < JD_RSTEPS; ++st) {
+                if (st == 0 || p < lim) {
+                    const bool isdc = k == 0;
+                    const uint32_t top = R.top();
+                    const uint32_t e = lookup_entry<true>(T, tb, isdc, top);
+                    fl |= e;
+                    const uint32_t tot = e & 31u;
+                    /* DC difference (src/decoding.c:44), added to the sum of the unit's component */
+                    int d = extend_at(top, tot, (e >> 8) & 15u);
+                    d = isdc ? d : 0;
+                    dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
+                    p += tot;
+                    k = isdc ? 1u : k + ((e >> 5) & 127u);
+                    R.consume(tot);
+                    /* end of the data unit, branch-free; the descriptor is re-read in every step so
+                     * that no divergent merge copies it around */
+                    const bool end = k >= 64u;
+                    k = end ? 0u : k; n += end ? 1 : 0; b = end ? tb.nb : b;
+                }
+                tb = T.blk[b];
+            }
+            R.refill();
         }
         if (c < JD_CP && !matched) {
             if (p >= mark) {
                 const uint32_t st = p | (k << 16) | (b << 24);
-                tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tw |= acs;
-                cp_val[c] = make_int4(n | ((acs & 8u) ? JD_CNT_WIDE : 0), dc0, dc1, dc2); /* also on a match: the way here was new */
+                tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tf |= fl;
+                cp_val[c] = make_int4(n | ((fl & LE_WIDE) ? JD_CNT_WIDE : 0), dc0, dc1, dc2); /* also on a match: the way here was new */
                 if (COMPARE && st == old[c]) {
 #pragma unroll
                     for (uint32_t i = c + 1; i <= JD_CP; ++i) {
                         const int4 v = cp_val[i];
                         tn += v.x & (JD_CNT_WIDE - 1); t0 += v.y; t1 += v.z; t2 += v.w;
-                        tw |= (v.x & JD_CNT_WIDE) ? 8u : 0u;
+                        tf |= (v.x & JD_CNT_WIDE) ? LE_WIDE : 0u;
                     }
                     matched = true;
                     p = 0xFFFFFFFFu; /* no further step */
                 } else {
                     cp_state[c] = st;
                 }
-                n = dc0 = dc1 = dc2 = 0; acs = 0;
+                n = dc0 = dc1 = dc2 = 0; fl &= LE_BAD; /* the error flag belongs to the exit state of the whole decode */
             } else { /* the segment ends before this checkpoint */
                 cp_state[c] = JD_CP_NONE;
                 cp_val[c] = make_int4(0, 0, 0, 0);
@@ -543,12 +605,12 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     if (matched) {
         r.exit_state = old_exit;
     } else {
-        cp_val[JD_CP] = make_int4(n | ((acs & 8u) ? JD_CNT_WIDE : 0), dc0, dc1, dc2);
-        tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tw |= acs;
+        cp_val[JD_CP] = make_int4(n | ((fl & LE_WIDE) ? JD_CNT_WIDE : 0), dc0, dc1, dc2);
+        tn += n; t0 += dc0; t1 += dc1; t2 += dc2; tf |= fl;
         const uint32_t ovs = p >= JD_SEG_BITS ? p - JD_SEG_BITS : 0u;
-        r.exit_state = JD_ST_PACK(ovs, k, b) | ((bad & 0x2000u) ? JD_ST_BAD : 0u);
+        r.exit_state = JD_ST_PACK(ovs, k, b) | ((tf & LE_BAD) ? JD_ST_BAD : 0u);
     }
-    r.n = tn; r.dc0 = t0; r.dc1 = t1; r.dc2 = t2; r.wide = (tw >> 3) & 1u;
+    r.n = tn | ((tf & LE_WIDE) ? JD_CNT_WIDE : 0); r.dc0 = t0; r.dc1 = t1; r.dc2 = t2;
     return r;
 }
 
@@ -563,37 +625,65 @@ __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTabl
     R.init(p);
     BlkDesc tb = T.blk[b];
     while (p < valid) {
-        const uint32_t top = R.top();
-        const bool isdc = (k == 0);
-        const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
-        const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
-        k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : k + run + 1u);
-        const uint32_t tot = len + size;
-        p += tot;
-        R.consume(tot);
-        const bool end = k >= 64u;
-        const uint32_t nb = (b + 1 == T.bpm) ? 0 : b + 1;
-        k = end ? 0u : k; b = end ? nb : b;
-        tb = T.blk[b];
+#pragma unroll
+        for (int st = 0; st < JD_RSTEPS; ++st) {
+            if (st == 0 || p < valid) {
+                const bool isdc = k == 0;
+                const uint32_t e = lookup_entry<true>(T, tb, isdc, R.top());
+                const uint32_t tot = e & 31u;
+                p += tot;
+                k = isdc ? 1u : k + ((e >> 5) & 127u);
+                R.consume(tot);
+                const bool end = k >= 64u;
+                k = end ? 0u : k; b = end ? tb.nb : b;
+            }
+            tb = T.blk[b];
+        }
+        R.refill();
     }
     return JD_ST_PACK(p - valid, k, b);
 }
 
-__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im, int sel,
+/* copy the lookup part of nslots tables into LDS, resolved entries rewritten for the kernel's
+ * decode loop (LIGHT or write form), and build the per-unit descriptors */
+template <bool LIGHT>
+__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im,
                                              uint32_t nslots = JD_LUT_SLOTS) {
-    constexpr uint32_t HOT16 = sizeof(jd_lut_hot) / 16, LUT16 = sizeof(jd_lut) / 16;
-    const uint4 *src = reinterpret_cast<const uint4 *>(g_lut);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
-    for (uint32_t i = threadIdx.x; i < nslots * HOT16; i += blockDim.x)
-        dst[i] = src[(i / HOT16) * LUT16 + i % HOT16];
+    constexpr uint32_t HOT32 = sizeof(jd_lut_hot) / 4, LUT32 = sizeof(jd_lut) / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_lut);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_lut);
+    /* two entries per lane and round, not unrolled: this loop must not set the kernel's register count */
+#pragma unroll 1
+    for (uint32_t slot = 0; slot < nslots; ++slot) {
+        const bool is_dc = g_lut[slot].is_dc != 0;
+#pragma unroll 1
+        for (uint32_t i = threadIdx.x; i < HOT32; i += blockDim.x) {
+            const uint32_t v = src[slot * LUT32 + i];
+            dst[slot * HOT32 + i] = convert_entry<LIGHT>(v & 0xFFFFu, is_dc) | (convert_entry<LIGHT>(v >> 16, is_dc) << 16);
+        }
+    }
     if (threadIdx.x < JD_MAX_BPM) {
-        const uint32_t dcs = im.blk_dc[threadIdx.x], acs = im.blk_ac[threadIdx.x], c = im.blk_comp[threadIdx.x];
+        const uint32_t dcs = im.blk_dc[threadIdx.x], acs = im.blk_ac[threadIdx.x];
+        const uint32_t c = im.blk_comp[threadIdx.x];
+        const int sel = LIGHT ? 1 : -1;
         BlkDesc d;
         d.dc_off = dcs * (uint32_t)sizeof(jd_lut_hot); d.ac_off = acs * (uint32_t)sizeof(jd_lut_hot);
+        d.slots = dcs | (acs << 4);
+        d.nb = threadIdx.x + 1u == im.bpm ? 0u : threadIdx.x + 1u;
         d.e0 = c == 0 ? sel : 0; d.e1 = c == 1 ? sel : 0; d.e2 = c == 2 ? sel : 0;
-        d.slots = dcs | (acs << 4); d.pad = d.pad2 = 0;
+        d.pad = 0;
         s_blk[threadIdx.x] = d;
     }
+}
+
+/* the (image, first segment) descriptor of this wave, in scalar registers: everything derived
+ * from it (image record, stream base) is then read and computed once per wave, not per lane */
+__device__ __forceinline__ jd_huff_wg wave_desc(const jd_huff_wg *__restrict__ wgs, uint32_t waves) {
+    const jd_huff_wg w = wgs[blockIdx.x * waves + (threadIdx.x >> 6)];
+    jd_huff_wg u;
+    u.img = __builtin_amdgcn_readfirstlane(w.img);
+    u.seg0 = __builtin_amdgcn_readfirstlane(w.seg0);
+    return u;
 }
 
 /*
@@ -617,7 +707,7 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
  * while a few lanes of its work-group decode again (measured: 5.6 -> 3 ms per 2048 images).
  *
  * st_in / st_exit / cnt: per segment the start state used, the exit state reached, and
- * (data units completed, DC difference sums per component).
+ * (data units completed | JD_CNT_WIDE, DC difference sums per component).
  */
 __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
@@ -634,12 +724,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
 
     /* one descriptor per wave; the waves of a work-group may serve different images, whose
      * tables and unit layout the plan made sure are the same (staged from the first wave's) */
-    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)];
+    const jd_huff_wg wg = wave_desc(wgs, JD_WG_WAVES);
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
     if (!__syncthreads_or(wg.seg0 < n_segs)) return; /* seg_cap is an upper bound: trailing groups are empty */
     const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
-    stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, 1);
+    stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
     __syncthreads();
     if (wg.seg0 >= n_segs) return;
     const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
@@ -663,7 +753,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
      * per checkpoint interval, so that a repair that stops at a checkpoint takes the flags of
      * the part it did not decode again from the decode that did; k_seg_scan gathers them once
      * the start states are final (a decode from a wrong start state sees garbage symbols). */
-    cnt[gs] = make_int4(r.n | (r.wide ? JD_CNT_WIDE : 0), r.dc0, r.dc1, r.dc2);
+    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
 }
 
 __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__restrict__ imgs,
@@ -673,7 +763,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__re
                                                             const uint32_t *__restrict__ st_exit,
                                                             uint32_t *__restrict__ list,
                                                             uint32_t *__restrict__ list_cnt) {
-    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)];
+    const jd_huff_wg wg = wave_desc(wgs, JD_WG_WAVES);
     const jd_image &im = imgs[wg.img];
     const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
     bool broken = false;
@@ -707,12 +797,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[JD_LUT_SLOTS];
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
 
-    const jd_huff_wg wg = wgs[blockIdx.x * JD_WG_WAVES + (threadIdx.x >> 6)]; /* here: entries [seg0, seg0 + 64) of the image's list */
+    const jd_huff_wg wg = wave_desc(wgs, JD_WG_WAVES); /* here: entries [seg0, seg0 + 64) of the image's list */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_list = min(list_cnt[wg.img], im.n_segs);
     if (!__syncthreads_or(wg.seg0 < n_list)) return; /* the usual case from the second round on */
     const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
-    stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, 1);
+    stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
     __syncthreads();
     if (wg.seg0 >= n_list) return;
     const uint32_t idx = wg.seg0 + (threadIdx.x & 63u);
@@ -729,7 +819,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
                                              st_exit[gs] & ~JD_ST_BAD);
     st_in[gs] = in;
     st_exit[gs] = r.exit_state;
-    cnt[gs] = make_int4(r.n | (r.wide ? JD_CNT_WIDE : 0), r.dc0, r.dc1, r.dc2);
+    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
 }
 
 /* ============================================================================================
@@ -824,12 +914,19 @@ __constant__ uint8_t c_zz_cm[64];
  * k_huff_write: one lane per segment again, now from the true start state.  A data unit is
  * written entirely by the lane in whose segment it STARTS (that lane runs on into the next
  * segment to finish its last unit; a lane that starts in the middle of a unit decodes the rest
- * of it without storing).  Coefficients are assembled in a 128-byte LDS buffer per lane; after
- * every symbol step the wave flushes the units that were completed in that step together:
- * 8 lanes per unit write its 128-byte line with one 16-byte store each (full, coalesced lines
- * instead of ~12 scattered 2-byte stores per unit) and clear the buffer for the next unit.
+ * of it without storing).  Coefficients are assembled in a per-lane LDS buffer (128 bytes of
+ * int16, or 64 bytes of int8 in the NARROW instantiation, where the DC value travels through the
+ * flush queue).  A loop iteration decodes up to JD_WSTEPS symbols per lane -- a lane that has
+ * completed a unit it owns pauses for the rest of the iteration, its buffer still holds that
+ * unit -- and then the wave flushes the units completed in the iteration together: 8 lanes per
+ * unit write its 128-byte line with one 16-byte store each (full, coalesced lines instead of
+ * ~12 scattered 2-byte stores per unit) and clear the buffer.
+ * (Measured and rejected in round 2: DC differences into a side array, one 4-byte store per unit,
+ * resolved by a scan kernel afterwards so that no decode has to read DC magnitudes: the 200 M
+ * partial-line stores of a 4096 x 1080p batch cost 4.4 ms.)
  */
 #define WBUF_BYTES 128u
+#define JD_WSTEPS JD_RSTEPS
 __device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
     /* 16-byte chunks rotated by the lane number: both the lanes' scattered stores and the
      * 8-lanes-per-unit flush spread over the LDS banks */
@@ -838,8 +935,8 @@ __device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
 
 /* NARROW: 64-byte unit buffers of int8 (24 instead of 16 waves per CU with 8-wave work-groups)
  * for images none of whose AC coefficients needs more than 7 magnitude bits (the light decodes
- * tell, `wide`); the DC value travels through the flush queue.  The wide instantiation is
- * launched beside it and takes the other images; each skips the waves that are not its own. */
+ * tell, `wide`).  The wide instantiation is launched beside it and takes the other images; each
+ * skips the waves that are not its own. */
 __device__ __forceinline__ uint32_t nbuf_addr(uint32_t lane, uint32_t idx) {
     return lane * 64u + ((((idx >> 3) + lane) & 7u) << 3) + (idx & 7u);
 }
@@ -857,8 +954,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                                                            uint32_t *__restrict__ status,
                                                            uint32_t *__restrict__ wide) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
-    /* <4 waves, 6 table slots>: 51 KB, 3 work-groups = 12 waves per CU; <8, 4> (no image of the
-     * batch uses more than 4 slots): 78 KB, 2 work-groups = 16 waves per CU */
+    /* <4 waves, 6 table slots>: 3 work-groups = 12 waves per CU wide, 4 narrow; <8, 4> (no image of
+     * the batch uses more than 4 slots): 2 work-groups = 16 waves per CU wide, 3 = 24 narrow */
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[SLOTS];
     constexpr uint32_t UB = NARROW ? 64u : WBUF_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[64 * WAVES * UB];
@@ -868,7 +965,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     __shared__ BlkDesc s_blk[JD_MAX_BPM];
     __shared__ uint8_t s_cm[64];
 
-    const jd_huff_wg wg = wgs[blockIdx.x * WAVES + (threadIdx.x >> 6)]; /* per wave, see k_huff_first */
+    const jd_huff_wg wg = wave_desc(wgs, WAVES); /* per wave, see k_huff_first */
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
     /* SPLIT: narrow and wide instantiation run side by side, each on its own images */
@@ -879,7 +976,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const jd_lut *const g_lut = luts + im.lut_off;
     {
         const jd_image &im0 = imgs[wgs[blockIdx.x * WAVES].img];
-        stage_tables(s_lut, s_blk, luts + im0.lut_off, im0, -1, SLOTS);
+        stage_tables<false>(s_lut, s_blk, luts + im0.lut_off, im0, SLOTS);
     }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
@@ -918,8 +1015,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
     BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
     R.init(p);
-    const uint32_t bpm = im.bpm;
-    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), g_lut, s_blk, bpm};
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), g_lut, s_blk, 0u};
     BlkDesc tb = s_blk[b];
     bool own = (k == 0); /* does this lane own the data unit it is in? */
     int dcv = 0;         /* NARROW: DC value of the unit in progress */
@@ -928,48 +1024,60 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
 
     /* a unit is decoded while it STARTED before the end of the segment */
     active = active && (k != 0 || p < valid) && B < limit;
+    /* Everything the loop reads that came from memory is "used" here, so that the compiler waits
+     * for those loads BEFORE the loop.  gfx9 counts loads and stores in one in-order counter: a
+     * wait for a pre-loop load placed inside the loop is a wait for all but the newest few memory
+     * operations, i.e. for the flush stores of the previous iteration, in every iteration. */
+    asm volatile("" ::"v"(avail), "v"(valid), "v"(limit), "v"(B), "v"(p), "v"(k), "v"(b), "v"(R.own), "v"(R.dnx), "v"(cbase), "v"(pr0), "v"(pr1), "v"(pr2));
     while (__any(active)) {
-        bool finished = false; /* an OWNED unit was completed in this step */
+        bool finished = false; /* an OWNED unit was completed in this iteration */
         int fB = 0;            /* ... and this is its index */
-        if (active) {
-            const uint32_t top = R.top();
-            const bool isdc = (k == 0);
-            const uint32_t e = lookup_entry(T, isdc ? tb.dc_off : tb.ac_off, isdc ? (tb.slots & 15u) : (tb.slots >> 4), top);
-            const uint32_t len = e & 31u, size = (e >> 5) & 15u, run = (e >> 9) & 15u;
-            const uint32_t tot = len + size;
-            if (p + tot > avail) { flags |= JDGPU_IMG_EOF; active = false; }        /* src/bitstream.c:17 */
-            else if (e & 0x2000u) { flags |= JDGPU_IMG_NOSYMBOL; active = false; }  /* src/hufftree.c:69,72 */
-            else {
-                int val = extend_top(top << len, size);
+#pragma unroll
+        for (int s = 0; s < JD_WSTEPS; ++s) {
+            if (active && !finished) {
+                const uint32_t top = R.top();
+                const bool isdc = (k == 0);
+                const uint32_t e = lookup_entry<false>(T, tb, isdc, top);
+                const uint32_t len = (e & 15u) + 1u, size = (e >> 4) & 15u, kinc = (e >> 8) & 127u;
+                const uint32_t tot = len + size;
+                /* src/bitstream.c:17 (the data ends inside this symbol) before src/hufftree.c:69,72
+                 * (no such code): the reference reads bit by bit and meets the end first */
+                const uint32_t err = (p + tot > avail) ? (uint32_t)JDGPU_IMG_EOF : (kinc == 0u ? (uint32_t)JDGPU_IMG_NOSYMBOL : 0u);
+                flags |= err;
+                const bool ok = err == 0u;
+                int val = extend_at(top, tot, size);
                 /* DC: predictor of the unit's component (src/decoding.c:44-46; quantised, the
                  * multiply is in k_pixel) */
-                const int d = isdc ? val : 0;
+                const int d = (isdc && ok) ? val : 0;
                 pr0 += d & tb.e0; pr1 += d & tb.e1; pr2 += d & tb.e2;
                 const int pv = (pr0 & tb.e0) | (pr1 & tb.e1) | (pr2 & tb.e2);
                 val = isdc ? pv : val;
-                const uint32_t kk = isdc ? 0u : k + run;
-                const bool store = isdc || (own && size != 0 && kk < 64u);          /* src/decoding.c:65 */
-                k = isdc ? 1u : ((size == 0 && run != 15u) ? 64u : kk + 1u);
+                const uint32_t kk = k + kinc - 1u;            /* zigzag index of this symbol's coefficient (DC: 0) */
                 if (NARROW) {
                     dcv = isdc ? val : dcv;
-                    ovf |= isdc ? 0u : (uint32_t)(val + 128);
-                    /* a DC step stores a byte of its value at index 0; the flush puts the real one there */
-                    if (store) *reinterpret_cast<int8_t *>(s_buf + nbuf_addr(lane, s_cm[kk & 63u])) = (int8_t)val;
+                    /* kk in 1..63: an AC coefficient inside the unit (src/decoding.c:65; a run past 63 is dropped) */
+                    if (ok && own && size != 0u && kk - 1u < 63u) {
+                        ovf |= (uint32_t)(val + 128);
+                        *reinterpret_cast<int8_t *>(s_buf + nbuf_addr(lane, s_cm[kk])) = (int8_t)val;
+                    }
                 } else {
-                    if (store) *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
+                    if (ok && (isdc || (own && size != 0u && kk < 64u)))
+                        *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
                 }
                 p += tot;
-                R.advance(tot);
-                if (k >= 64u) {
-                    finished = own; fB = B;
-                    k = 0; own = true; ++B;
-                    b = (b + 1 == bpm) ? 0 : b + 1;
-                }
+                k += kinc;
+                R.consume(tot);
+                const bool end = ok && k >= 64u;
+                const uint32_t nb = tb.nb;
+                finished = end && own;
+                fB = B;
+                B += end ? 1 : 0; own = own || end; k = end ? 0u : k; b = end ? nb : b;
+                active = ok && (k != 0 || p < valid) && B < limit;
             }
+            tb = s_blk[b]; /* every step, all lanes: no divergent merge copies the descriptor around */
         }
-        tb = s_blk[b]; /* every step, all lanes: no divergent merge copies the descriptor around */
-        R.prefetch(); /* all lanes, outside the divergent step */
-        /* ---- flush the units completed in this step (wave-synchronous) ---- */
+        R.refill(); /* all lanes, outside the divergent steps */
+        /* ---- flush the units completed in this iteration (wave-synchronous) ---- */
         uint64_t fm = __ballot(finished);
         if (fm) {
             if (finished) {
@@ -1009,7 +1117,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        active = active && (k != 0 || p < valid) && B < limit;
     }
     /* data ended before the interval's data units did */
     if (!flags && seg < n_segs && B < limit && is_last) flags |= JDGPU_IMG_EOF;
