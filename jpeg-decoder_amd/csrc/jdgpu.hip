@@ -499,7 +499,11 @@ struct BitReader {
         w1 = s == 2u ? a : w1;                     /* two shifts left w1 = w2 = the old w2 */
         w2 = s == 2u ? b : (s == 1u ? a : w2);
         c += s; s = 0;
+#ifdef JD_ABL_L1LOAD   /* ablation: the loads stay, but always hit the same line */
+        qa = word(c & 3u); qb = word((c + 1u) & 3u);
+#else
         qa = word(c); qb = word(c + 1u);
+#endif
     }
 };
 
@@ -1079,6 +1083,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
         R.refill(); /* all lanes, outside the divergent steps */
         /* ---- flush the units completed in this iteration (wave-synchronous) ---- */
         uint64_t fm = __ballot(finished);
+#ifdef JD_ABL_NOFLUSH
+        fm = 0;
+#endif
         if (fm) {
             if (finished) {
                 uint32_t r = __popcll(fm & ((1ull << wlane) - 1ull));
@@ -1110,8 +1117,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 }
                 /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
                 uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64 + sub * 8);
+#ifdef JD_ABL_NOSTORE   /* ablation: the stores go to one small region */
+                out = reinterpret_cast<uint32_t *>(cbase + (size_t)(blk & 1023u) * 64 + sub * 8);
+#endif
+#ifdef JD_ABL_NOSTORE2  /* ablation: one lane in 64 stores */
+                if (v.x == 0x12345678u)
+#endif
+                {
+#ifdef JD_ABL_PLAINSTORE
+                *reinterpret_cast<uint4 *>(out) = v;
+#else
                 __builtin_nontemporal_store(v.x, out); __builtin_nontemporal_store(v.y, out + 1);
                 __builtin_nontemporal_store(v.z, out + 2); __builtin_nontemporal_store(v.w, out + 3);
+#endif
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1144,18 +1163,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
  * out[x] = S * sum_u in[u] * T[u][x];  T[u][7-x] = (-1)^u T[u][x].  S is a power of two, so
  * scaling the constants is exact and commutes with every rounding (S = 1/4 folds the
  * reference's final "sum / 4", src/decoding.c:83, into the second pass). */
+/* pix_real: the arithmetic type of the IDCT.  double is the product (byte-identical to the reference on
+ * every fixture); JD_ABL_PIX_F32 builds the all-float variant for the round-2 measurement of what
+ * f32 would buy, never shipped. */
+#ifdef JD_ABL_PIX_F32
+typedef float pix_real;
+#else
+typedef double pix_real;
+#endif
 template <int QUARTER>
-__device__ __forceinline__ void idct8(const double in[8], double out[8]) {
-    constexpr double S = QUARTER ? 0.25 : 1.0;
-    double e0 = in[0] * (T0 * S), e4 = in[4] * (T0 * S);
-    double a0 = e0 + e4, a1 = e0 - e4;                             /* u = 0, 4 */
-    double b0 = fma(in[2], T2 * S, in[6] * (T6 * S));              /* u = 2, 6 at x = 0 */
-    double b1 = fma(in[2], T6 * S, -(in[6] * (T2 * S)));           /* at x = 1 */
-    double E0 = a0 + b0, E3 = a0 - b0, E1 = a1 + b1, E2 = a1 - b1;
-    double O0 = fma(in[1], T1 * S, fma(in[3], T3 * S, fma(in[5], T5 * S, in[7] * (T7 * S))));
-    double O1 = fma(in[1], T3 * S, fma(in[3], -T7 * S, fma(in[5], -T1 * S, in[7] * (-T5 * S))));
-    double O2 = fma(in[1], T5 * S, fma(in[3], -T1 * S, fma(in[5], T7 * S, in[7] * (T3 * S))));
-    double O3 = fma(in[1], T7 * S, fma(in[3], -T5 * S, fma(in[5], T3 * S, in[7] * (-T1 * S))));
+__device__ __forceinline__ void idct8(const pix_real in[8], pix_real out[8]) {
+    constexpr pix_real S = QUARTER ? 0.25 : 1.0;
+    pix_real e0 = in[0] * (pix_real)(T0 * S), e4 = in[4] * (pix_real)(T0 * S);
+    pix_real a0 = e0 + e4, a1 = e0 - e4;                             /* u = 0, 4 */
+    pix_real b0 = fma(in[2], (pix_real)(T2 * S), in[6] * (pix_real)(T6 * S));              /* u = 2, 6 at x = 0 */
+    pix_real b1 = fma(in[2], (pix_real)(T6 * S), -(in[6] * (pix_real)(T2 * S)));           /* at x = 1 */
+    pix_real E0 = a0 + b0, E3 = a0 - b0, E1 = a1 + b1, E2 = a1 - b1;
+    pix_real O0 = fma(in[1], (pix_real)(T1 * S), fma(in[3], (pix_real)(T3 * S), fma(in[5], (pix_real)(T5 * S), in[7] * (pix_real)(T7 * S))));
+    pix_real O1 = fma(in[1], (pix_real)(T3 * S), fma(in[3], (pix_real)(-T7 * S), fma(in[5], (pix_real)(-T1 * S), in[7] * (pix_real)(-T5 * S))));
+    pix_real O2 = fma(in[1], (pix_real)(T5 * S), fma(in[3], (pix_real)(-T1 * S), fma(in[5], (pix_real)(T7 * S), in[7] * (pix_real)(T3 * S))));
+    pix_real O3 = fma(in[1], (pix_real)(T7 * S), fma(in[3], (pix_real)(-T5 * S), fma(in[5], (pix_real)(T3 * S), in[7] * (pix_real)(-T1 * S))));
     out[0] = E0 + O0; out[7] = E0 - O0;
     out[1] = E1 + O1; out[6] = E1 - O1;
     out[2] = E2 + O2; out[5] = E2 - O2;
@@ -1166,8 +1193,12 @@ __device__ __forceinline__ void idct8(const double in[8], double out[8]) {
  * RN(v) + 128 in the low mantissa word (|v| << 2^31): round-to-nearest, which equals lround
  * except on exact ties -- and a sum of products with the six-decimal table is never an exact
  * half-integer.  One f64 add, no conversion instruction. */
-__device__ __forceinline__ uint32_t to_sample(double v) {
+__device__ __forceinline__ uint32_t to_sample(pix_real v) {
+#ifdef JD_ABL_PIX_F32
+    int i = __float2int_rn(v) + 128;
+#else
     int i = __double2loint(v + (6755399441055744.0 + 128.0));
+#endif
     return (uint32_t)min(max(i, 0), 255);
 }
 
@@ -1209,46 +1240,66 @@ __device__ __forceinline__ int green_fix(const ChromaTerms &t, int Y) {
 
 __device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
 
-/* 4 pixels that share their chroma in pairs (4:2:0) or not (4:4:4) -> 12 channel values,
- * o[3 * pixel + channel] */
-struct Px4 { uint32_t o[12]; };
+/*
+ * 4 pixels -> their 12 output bytes, two pixels per instruction.  Px4: per channel the bytes of
+ * pixels (0, 2) and of pixels (1, 3), each pair in the low two bytes of a register -- what
+ * v_sat_pk_u8_i16 leaves when it clamps two 16-bit sums to 0..255 and packs them, which is the
+ * reference's clamp (src/image.c:34-36, 44-48) for two values at once.
+ */
+struct Px4 { uint32_t c02[3], c13[3]; };
+typedef short jd_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {   /* v_pk_add_u16 */
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jd_short2, a) + __builtin_bit_cast(jd_short2, b));
+}
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jd_short2, a) - __builtin_bit_cast(jd_short2, b));
+}
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t two_i16) {         /* {clamp(hi), clamp(lo)} -> bytes 1, 0 */
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
+    return r;
+}
+
+/* y4: the luma bytes of the 4 pixels; cbv / crv: their chroma (nterms == 2: pixels 0, 1 share
+ * entry 0 and pixels 2, 3 entry 2) */
 template <bool OUT_YCBCR>
 __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const uint32_t crv[4], int nterms) {
     Px4 r;
+    if (OUT_YCBCR) {
+        r.c02[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0200u); r.c13[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0301u);
+        r.c02[1] = cbv[0] | (cbv[2] << 8); r.c13[1] = cbv[1] | (cbv[3] << 8);
+        r.c02[2] = crv[0] | (crv[2] << 8); r.c13[2] = crv[1] | (crv[3] << 8);
+        return r;
+    }
     ChromaTerms ct[4];
-    if (!OUT_YCBCR) {
-        ct[0] = chroma_terms((int)cbv[0], (int)crv[0]);
-        if (nterms == 4) {
-            ct[1] = chroma_terms((int)cbv[1], (int)crv[1]);
-            ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
-            ct[3] = chroma_terms((int)cbv[3], (int)crv[3]);
-        } else {
-            ct[1] = ct[0];
-            ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
-            ct[3] = ct[2];
-        }
+    ct[0] = chroma_terms((int)cbv[0], (int)crv[0]);
+    ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
+    if (nterms == 4) {
+        ct[1] = chroma_terms((int)cbv[1], (int)crv[1]);
+        ct[3] = chroma_terms((int)cbv[3], (int)crv[3]);
+    } else {
+        ct[1] = ct[0];
+        ct[3] = ct[2];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int Y = (int)((y4 >> (8 * i)) & 255u);
-        if (OUT_YCBCR) { r.o[3 * i] = (uint32_t)Y; r.o[3 * i + 1] = cbv[i]; r.o[3 * i + 2] = crv[i]; }
-        else {
-            r.o[3 * i] = clamp255(Y + ct[i].dr);
-            r.o[3 * i + 1] = clamp255(Y + ct[i].dg);
-            r.o[3 * i + 2] = clamp255(Y + ct[i].db);
-        }
-    }
+    const uint32_t y02 = y4 & 0x00FF00FFu, y13 = (y4 >> 8) & 0x00FF00FFu;   /* two 16-bit lanes each */
+    uint32_t s02[3] = {pk_add16(y02, pack16(ct[0].dr, ct[2].dr)), pk_add16(y02, pack16(ct[0].dg, ct[2].dg)),
+                       pk_add16(y02, pack16(ct[0].db, ct[2].db))};
+    uint32_t s13[3] = {pk_add16(y13, pack16(ct[1].dr, ct[3].dr)), pk_add16(y13, pack16(ct[1].dg, ct[3].dg)),
+                       pk_add16(y13, pack16(ct[1].db, ct[3].db))};
     /* wave-uniform and almost never taken: a lane of the wave holds the exceptional chroma pair.
      * Kept a real branch (the empty asm stops the compiler from turning it into selects, which
-     * cost every wave 16 instructions per row). */
-    if (!OUT_YCBCR && __any((int)(ct[0].exc | ct[1].exc | ct[2].exc | ct[3].exc))) {
+     * cost every wave a dozen instructions per row). */
+    if (__any((int)(ct[0].exc | ct[1].exc | ct[2].exc | ct[3].exc))) {
         asm volatile("" ::: "memory");
+        int fix[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int Y = (int)((y4 >> (8 * i)) & 255u);
-            r.o[3 * i + 1] = clamp255(Y + ct[i].dg - green_fix(ct[i], Y));
-        }
+        for (int i = 0; i < 4; ++i) fix[i] = green_fix(ct[i], (int)((y4 >> (8 * i)) & 255u));
+        s02[1] = pk_sub16(s02[1], pack16(fix[0], fix[2]));
+        s13[1] = pk_sub16(s13[1], pack16(fix[1], fix[3]));
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r.c02[c] = sat_pk_u8(s02[c]); r.c13[c] = sat_pk_u8(s13[c]); }
     return r;
 }
 
@@ -1260,29 +1311,34 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
 template <uint32_t FMT>
 __device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t at, const Px4 &v, bool aligned,
                                           uint32_t npx) {
-    const uint32_t *o = v.o; /* at = y * width + x (< 2^32: both are 16-bit), plane = width * height */
-    if (FMT == JD_FMT_4) {
-        /* 16 bytes per lane, always aligned (x is a multiple of 4, images start on 256 bytes) */
-        uint32_t p[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = o[3 * i] | (o[3 * i + 1] << 8) | (o[3 * i + 2] << 16) | 0xFF000000u;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 4);
-        if (npx == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
-        else
-            for (uint32_t i = 0; i < npx; ++i) dst[i] = p[i];
-    } else if (FMT == JD_FMT_PLANAR) {
+    /* at = y * width + x (< 2^32: both are 16-bit), plane = width * height.  v_perm_b32 picks the
+     * output bytes: selector 0..3 = bytes of the second operand, 4..7 = of the first, 0x0D = 0xFF */
+    if (FMT == JD_FMT_PLANAR) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const uint32_t w = o[c] | (o[3 + c] << 8) | (o[6 + c] << 16) | (o[9 + c] << 24);
+            const uint32_t w = __builtin_amdgcn_perm(v.c13[c], v.c02[c], 0x05010400u);   /* pixels 0, 1, 2, 3 */
             uint8_t *dst = out + c * plane + at;
             if (aligned) *reinterpret_cast<uint32_t *>(dst) = w;       /* W % 4 == 0 */
             else
                 for (uint32_t i = 0; i < npx; ++i) dst[i] = (uint8_t)(w >> (8 * i));
         }
+        return;
+    }
+    const uint32_t rg02 = v.c02[0] | (v.c02[1] << 16);    /* R0 R2 G0 G2 */
+    const uint32_t br = v.c02[2] | (v.c13[0] << 16);      /* B0 B2 R1 R3 */
+    const uint32_t gb13 = v.c13[1] | (v.c13[2] << 16);    /* G1 G3 B1 B3 */
+    if (FMT == JD_FMT_4) {
+        /* 16 bytes per lane, always aligned (x is a multiple of 4, images start on 256 bytes) */
+        const uint32_t p[4] = {__builtin_amdgcn_perm(br, rg02, 0x0D040200u), __builtin_amdgcn_perm(gb13, br, 0x0D060402u),
+                               __builtin_amdgcn_perm(br, rg02, 0x0D050301u), __builtin_amdgcn_perm(gb13, br, 0x0D070503u)};
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 4);
+        if (npx == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
+        else
+            for (uint32_t i = 0; i < npx; ++i) dst[i] = p[i];
     } else {
-        const uint32_t w[3] = {o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24),
-                               o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24),
-                               o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24)};
+        const uint32_t w[3] = {__builtin_amdgcn_perm(br, rg02, 0x06040200u),      /* R0 G0 B0 R1 */
+                               __builtin_amdgcn_perm(rg02, gb13, 0x07050200u),    /* G1 B1 R2 G2 */
+                               __builtin_amdgcn_perm(gb13, br, 0x07050301u)};     /* B2 R3 G3 B3 */
         if (aligned) {
             uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 3);
             dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
@@ -1295,7 +1351,7 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t a
 #define SUB_PX 64u                 /* pixels per wave: each wave owns a 64-pixel-wide part of the strip */
 #define PIX_ROW (SUB_PX + 8u)      /* bytes per sample-tile row (+8 spreads the rows over banks) */
 #define PLANE_BYTES (32u * PIX_ROW) /* generic instantiation: up to 4 units = 32 sample rows per MCU row */
-#define TR_BLK 64u                 /* doubles per 8x8 block in the transpose buffer */
+#define TR_BLK 64u                 /* values per 8x8 block in the transpose buffer */
 
 #define WAVE_SYNC()                                                   \
     do {                                                              \
@@ -1323,7 +1379,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                uint8_t *__restrict__ pix,
                                                const uint32_t *__restrict__ status,
                                                uint32_t pix_rows) {
-    __shared__ __attribute__((aligned(16))) double s_tr[8 * JD_PIX_WAVES * TR_BLK];
+    __shared__ __attribute__((aligned(16))) pix_real s_tr[8 * JD_PIX_WAVES * TR_BLK];
     /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
     /* the layouts with an instantiation of their own: luma HSH+1 x VSH+1 units per MCU, chroma 1x1 */
     constexpr bool FAST = MODE != JD_PIX_GENERIC, GRAY = MODE == JD_PIX_GRAY;
@@ -1367,7 +1423,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
      * the 16 lanes (2 slots) that write step y hit 16 different bank pairs and the 32 lanes
      * (4 slots) that read step u hit 32 (searched exhaustively; the earlier swizzle
      * (u + y) ^ (s & 3) in the column made every write 2-way: 36 % of the kernel's LDS cycles) */
-    double *tr = s_tr + (wave * 8u + slot) * TR_BLK;
+    pix_real *tr = s_tr + (wave * 8u + slot) * TR_BLK;
     uint8_t *tile = s_tile[wave];
     const uint32_t sx = slot & 3u;
     __syncthreads();
@@ -1412,7 +1468,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
                 }
                 uint32_t m = 0, b = 0, meta = 0;
-                double col[8], t[8];
+                pix_real col[8], t[8];
                 if (act) {
                     const uint32_t jm = s_jmap[j]; m = jm & 255u; b = jm >> 8; meta = s_meta[b];
                     uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
@@ -1420,8 +1476,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
-                        col[2 * q] = (double)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                        col[2 * q + 1] = (double)__mul24(hi, (int)(qw[q] >> 16));
+                        col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                        col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
                     }
                     idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
 #pragma unroll

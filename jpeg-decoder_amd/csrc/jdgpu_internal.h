@@ -151,7 +151,9 @@ typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 
                                                                    JD_WG_WAVES consecutive entries form a work-group */
 #define JD_WG_WAVES    (JD_WG_SEGS / 64u)
 #define JD_NO_WAVE     0xFFFFFFFFu                             /* seg0 of a padding entry */
+#ifndef JD_WWG_WAVES_BIG
 #define JD_WWG_WAVES_BIG 8u                                    /* write kernel, batches whose images use ... */
+#endif
 #define JD_WWG_SLOTS_BIG 4u                                    /* ... at most this many table slots */
 typedef struct { uint32_t img; uint16_t mcu_row, mcu_col0; } jd_pix_wg; /* strip of jd_plan::pix_rows MCU rows from mcu_row */
 typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK stuffed bytes */

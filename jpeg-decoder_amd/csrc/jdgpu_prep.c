@@ -329,7 +329,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         /* ... and only when there are enough waves to fill the chip twice over with them (a batch
          * of thumbnails spreads better in 4-wave groups: C2 0.68 against 0.79 ms) */
         const char *force = getenv("JDGPU_WWG_WAVES");   /* tests: "8" / "4" take the other path where it is legal */
-        uint32_t want_big = force ? (uint32_t)(atoi(force) == 8) : (uint32_t)(all_waves >= 8192u);
+        uint32_t want_big = force ? (uint32_t)(atoi(force) != 4) : (uint32_t)(all_waves >= 8192u);
         P->wwg_waves = (max_slots <= JD_WWG_SLOTS_BIG && want_big) ? JD_WWG_WAVES_BIG : JD_WG_WAVES;
         uint32_t *first = malloc((n + MAXG + 1) * sizeof *first);
         if (!first) { free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
