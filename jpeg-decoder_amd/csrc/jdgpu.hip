@@ -1192,14 +1192,21 @@ __device__ __forceinline__ void idct8(const pix_real in[8], pix_real out[8]) {
 /* src/decoding.c:99: clamp(lround(v) + 128, 0, 255).  Adding 1.5 * 2^52 + 128 to v leaves
  * RN(v) + 128 in the low mantissa word (|v| << 2^31): round-to-nearest, which equals lround
  * except on exact ties -- and a sum of products with the six-decimal table is never an exact
- * half-integer.  One f64 add, no conversion instruction. */
-__device__ __forceinline__ uint32_t to_sample(pix_real v) {
+ * half-integer.  One f64 add, no conversion instruction; the clamp is done on pairs (below). */
+__device__ __forceinline__ int to_int128(pix_real v) {
 #ifdef JD_ABL_PIX_F32
-    int i = __float2int_rn(v) + 128;
+    return __float2int_rn(v) + 128;
 #else
-    int i = __double2loint(v + (6755399441055744.0 + 128.0));
+    return __double2loint(v + (6755399441055744.0 + 128.0));
 #endif
-    return (uint32_t)min(max(i, 0), 255);
+}
+__device__ __forceinline__ uint32_t cvt_pk_i16(int lo, int hi) {          /* v_cvt_pk_i16_i32: both saturated to 16 bits */
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
+}
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t two_i16) {         /* v_sat_pk_u8_i16: {clamp(hi), clamp(lo)} to 0..255 -> bytes 1, 0 */
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
+    return r;
 }
 
 /*
@@ -1255,11 +1262,6 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(jd_short2, a) - __builtin_bit_cast(jd_short2, b));
 }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
-__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t two_i16) {         /* {clamp(hi), clamp(lo)} -> bytes 1, 0 */
-    uint32_t r;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
-    return r;
-}
 
 /* y4: the luma bytes of the 4 pixels; cbv / crv: their chroma (nterms == 2: pixels 0, 1 share
  * entry 0 and pixels 2, 3 entry 2) */
@@ -1488,12 +1490,13 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 #pragma unroll
                     for (int u = 0; u < 8; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
                     idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
-                    uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx) {
-                        w0 |= to_sample(t[xx]) << (8 * xx);
-                        w1 |= to_sample(t[xx + 4]) << (8 * xx);
-                    }
+                    /* src/decoding.c:99 for two samples at a time: RN(v) + 128 as integers (to_int128),
+                     * saturated to 16 bits and then to 0..255 by the two packing instructions */
+                    const uint32_t p01 = sat_pk_u8(cvt_pk_i16(to_int128(t[0]), to_int128(t[1])));
+                    const uint32_t p23 = sat_pk_u8(cvt_pk_i16(to_int128(t[2]), to_int128(t[3])));
+                    const uint32_t p45 = sat_pk_u8(cvt_pk_i16(to_int128(t[4]), to_int128(t[5])));
+                    const uint32_t p67 = sat_pk_u8(cvt_pk_i16(to_int128(t[6]), to_int128(t[7])));
+                    const uint32_t w0 = p01 | (p23 << 16), w1 = p45 | (p67 << 16);
                     uint32_t row = ((meta >> 6) & 3u) * 8u + l;
                     uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
                     *reinterpret_cast<uint2 *>(&tile[(meta >> 12) * 64u + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
