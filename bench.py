@@ -364,8 +364,9 @@ def main():
             "pixel_stage": with_traffic(roof("pixel"), args.workload, args.layout, res["pixels_rank"]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stitch_retries": res["retries"],
-            "commit": git_head(),
         }
+        if git_head():
+            out["commit"] = git_head()
         extras = world == 1 and not args.lean and args.workload == "c3" and not args.batch
         if extras:
             pkg.trim()
