@@ -404,8 +404,10 @@ struct SegTables {
 template <bool LIGHT>
 __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top) {
     const uint32_t off = isdc ? desc.dc_off : desc.ac_off;
-    uint32_t e = *reinterpret_cast<const uint16_t *>(T.lut + off + ((top >> (32 - JD_LUT_BITS)) << 1));
-    if (__builtin_expect(e >= JD_LUT_LINK, 0)) {
+    /* read sign-extended: link entries (bit 15) are the negative ones, no mask needed to tell */
+    const int se = *reinterpret_cast<const int16_t *>(T.lut + off + ((top >> (32 - JD_LUT_BITS)) << 1));
+    uint32_t e = (uint32_t)se;
+    if (__builtin_expect(se < 0, 0)) {
         const uint32_t first = e & 0xFFFu;
         if (__builtin_expect(first == JD_LUT_NOSUB, 0)) {
             const uint32_t slot = isdc ? (desc.slots & 15u) : (desc.slots >> 4);
@@ -427,7 +429,8 @@ __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b)
  * below 2^(size-1) stands for mag - (2^size - 1): with m = 2^size - 1 that is 2 mag < m. */
 __device__ __forceinline__ int extend_at(uint32_t top, uint32_t tot, uint32_t size) {
     const uint32_t mag = __builtin_amdgcn_ubfe(top, 32u - tot, size);
-    const uint32_t m = (1u << size) - 1u;
+    uint32_t m;                                    /* (1 << size) - 1 */
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(m) : "v"(size));
     return (int)mag - (int)(mag + mag < m ? m : 0u);
 }
 
@@ -491,8 +494,8 @@ struct BitReader {
         const bool need = r < 0;
         w0 = need ? w1 : w0;
         w1 = need ? w2 : w1;
-        r += need ? 32 : 0;
-        s += need ? 1u : 0u;
+        s += (uint32_t)r >> 31;
+        r &= 31;                                   /* -31..-1 -> 1..31 */
     }
     __device__ __forceinline__ void refill() {
         const uint32_t a = __builtin_bswap32(qa), b = __builtin_bswap32(qb);
