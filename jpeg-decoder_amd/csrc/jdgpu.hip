@@ -384,8 +384,7 @@ __device__ __forceinline__ uint32_t convert_entry(uint32_t e, bool is_dc) {
 
 /* per data unit of the MCU, in LDS: byte offsets of the unit's DC / AC table in the LDS copy,
  * slots = dc slot | ac slot << 4 (canonical fallback only), nb = the unit after it in the MCU;
- * e0..e2 select the unit's component: 1 / 0 (light decodes, multiplied) or -1 / 0 (k_huff_write,
- * used as masks) */
+ * e0..e2 select the unit's component: 1 / 0, multiplied */
 struct __attribute__((aligned(16))) BlkDesc {
     uint32_t dc_off, ac_off, slots, nb;
     int e0, e1, e2;
@@ -672,7 +671,7 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
     if (threadIdx.x < JD_MAX_BPM) {
         const uint32_t dcs = im.blk_dc[threadIdx.x], acs = im.blk_ac[threadIdx.x];
         const uint32_t c = im.blk_comp[threadIdx.x];
-        const int sel = LIGHT ? 1 : -1;
+        const int sel = 1;
         BlkDesc d;
         d.dc_off = dcs * (uint32_t)sizeof(jd_lut_hot); d.ac_off = acs * (uint32_t)sizeof(jd_lut_hot);
         d.slots = dcs | (acs << 4);
@@ -934,19 +933,18 @@ __constant__ uint8_t c_zz_cm[64];
  */
 #define WBUF_BYTES 128u
 #define JD_WSTEPS JD_RSTEPS
-__device__ __forceinline__ uint32_t wbuf_addr(uint32_t lane, uint32_t idx) {
-    /* 16-byte chunks rotated by the lane number: both the lanes' scattered stores and the
-     * 8-lanes-per-unit flush spread over the LDS banks */
-    return lane * WBUF_BYTES + ((((idx >> 3) + lane) & 7u) << 4) + ((idx & 7u) << 1);
+__device__ __forceinline__ uint32_t wbuf_key(uint32_t lane) {
+    /* 16-byte chunks permuted by the lane number (XOR on the chunk index): both the lanes'
+     * scattered stores and the 8-lanes-per-unit flush spread over the LDS banks, and the address of
+     * coefficient idx is ONE instruction: (idx * 2) ^ key */
+    return lane * WBUF_BYTES + ((lane & 7u) << 4);
 }
 
 /* NARROW: 64-byte unit buffers of int8 (24 instead of 16 waves per CU with 8-wave work-groups)
  * for images none of whose AC coefficients needs more than 7 magnitude bits (the light decodes
  * tell, `wide`).  The wide instantiation is launched beside it and takes the other images; each
  * skips the waves that are not its own. */
-__device__ __forceinline__ uint32_t nbuf_addr(uint32_t lane, uint32_t idx) {
-    return lane * 64u + ((((idx >> 3) + lane) & 7u) << 3) + (idx & 7u);
-}
+__device__ __forceinline__ uint32_t nbuf_key(uint32_t lane) { return lane * 64u + ((lane & 7u) << 3); } /* address = idx ^ key */
 template <uint32_t WAVES, uint32_t SLOTS, bool NARROW, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
@@ -1028,6 +1026,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     int dcv = 0;         /* NARROW: DC value of the unit in progress */
     uint32_t ovf = 0;    /* NARROW: an AC value that does not fit (cannot happen when `wide` is complete) */
     int16_t *const cbase = coef + (size_t)im.blk_off * 64;
+    const uint32_t bkey = NARROW ? nbuf_key(lane) : wbuf_key(lane);
 
     /* a unit is decoded while it STARTED before the end of the segment */
     active = active && (k != 0 || p < valid) && B < limit;
@@ -1048,16 +1047,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 const uint32_t len = (e & 15u) + 1u, size = (e >> 4) & 15u, kinc = (e >> 8) & 127u;
                 const uint32_t tot = len + size;
                 /* src/bitstream.c:17 (the data ends inside this symbol) before src/hufftree.c:69,72
-                 * (no such code): the reference reads bit by bit and meets the end first */
-                const uint32_t err = (p + tot > avail) ? (uint32_t)JDGPU_IMG_EOF : (kinc == 0u ? (uint32_t)JDGPU_IMG_NOSYMBOL : 0u);
-                flags |= err;
-                const bool ok = err == 0u;
+                 * (no such code): the reference reads bit by bit and meets the end first.  The flags
+                 * are set in a branch that is almost never taken; `ok` gates the side effects. */
+                const bool ok = p + tot <= avail && kinc != 0u;
+                if (__builtin_expect(!ok, 0)) flags |= (p + tot > avail) ? (uint32_t)JDGPU_IMG_EOF : (uint32_t)JDGPU_IMG_NOSYMBOL;
                 int val = extend_at(top, tot, size);
                 /* DC: predictor of the unit's component (src/decoding.c:44-46; quantised, the
-                 * multiply is in k_pixel) */
-                const int d = (isdc && ok) ? val : 0;
-                pr0 += d & tb.e0; pr1 += d & tb.e1; pr2 += d & tb.e2;
-                const int pv = (pr0 & tb.e0) | (pr1 & tb.e1) | (pr2 & tb.e2);
+                 * multiply is in k_pixel); e0..e2 are 1 for the unit's component, else 0 */
+                const int d = isdc ? val : 0;
+                pr0 = mad24(d, tb.e0, pr0); pr1 = mad24(d, tb.e1, pr1); pr2 = mad24(d, tb.e2, pr2);
+                const int pv = mad24(pr0, tb.e0, mad24(pr1, tb.e1, __mul24(pr2, tb.e2)));
                 val = isdc ? pv : val;
                 const uint32_t kk = k + kinc - 1u;            /* zigzag index of this symbol's coefficient (DC: 0) */
                 if (NARROW) {
@@ -1065,11 +1064,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                     /* kk in 1..63: an AC coefficient inside the unit (src/decoding.c:65; a run past 63 is dropped) */
                     if (ok && own && size != 0u && kk - 1u < 63u) {
                         ovf |= (uint32_t)(val + 128);
-                        *reinterpret_cast<int8_t *>(s_buf + nbuf_addr(lane, s_cm[kk])) = (int8_t)val;
+                        *reinterpret_cast<int8_t *>(s_buf + (s_cm[kk] ^ bkey)) = (int8_t)val;
                     }
                 } else {
                     if (ok && (isdc || (own && size != 0u && kk < 64u)))
-                        *reinterpret_cast<int16_t *>(s_buf + wbuf_addr(lane, s_cm[kk & 63u])) = (int16_t)val;
+                        *reinterpret_cast<int16_t *>(s_buf + ((2u * s_cm[kk & 63u]) ^ bkey)) = (int16_t)val;
                 }
                 p += tot;
                 k += kinc;
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 uint32_t blk = s_qblk[wbase + g];
                 uint4 v;
                 if (NARROW) {
-                    uint2 *lp = reinterpret_cast<uint2 *>(s_buf + src * 64u + (((sub + src) & 7u) << 3));
+                    uint2 *lp = reinterpret_cast<uint2 *>(s_buf + ((sub << 3) ^ nbuf_key(src)));
                     const uint2 n8 = *lp;
                     *lp = make_uint2(0, 0);
                     auto widen = [](uint32_t x, uint32_t sh) { /* bytes sh, sh+1 of x -> two int16 */
@@ -1114,7 +1113,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                     v = make_uint4(widen(n8.x, 0), widen(n8.x, 2), widen(n8.y, 0), widen(n8.y, 2));
                     if (sub == 0) v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)s_qdc[wbase + g];
                 } else {
-                    uint4 *lp = reinterpret_cast<uint4 *>(s_buf + src * WBUF_BYTES + (((sub + src) & 7u) << 4));
+                    uint4 *lp = reinterpret_cast<uint4 *>(s_buf + ((sub << 4) ^ wbuf_key(src)));
                     v = *lp;
                     *lp = make_uint4(0, 0, 0, 0);
                 }
