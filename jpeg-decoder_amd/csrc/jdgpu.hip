@@ -1180,8 +1180,8 @@ typedef double pix_real;
 template <int QUARTER>
 __device__ __forceinline__ void idct8(const pix_real in[8], pix_real out[8]) {
     constexpr pix_real S = QUARTER ? 0.25 : 1.0;
-    pix_real e0 = in[0] * (pix_real)(T0 * S), e4 = in[4] * (pix_real)(T0 * S);
-    pix_real a0 = e0 + e4, a1 = e0 - e4;                             /* u = 0, 4 */
+    pix_real e0 = in[0] * (pix_real)(T0 * S);
+    pix_real a0 = fma(in[4], (pix_real)(T0 * S), e0), a1 = fma(in[4], (pix_real)(-T0 * S), e0);   /* u = 0, 4 */
     pix_real b0 = fma(in[2], (pix_real)(T2 * S), in[6] * (pix_real)(T6 * S));              /* u = 2, 6 at x = 0 */
     pix_real b1 = fma(in[2], (pix_real)(T6 * S), -(in[6] * (pix_real)(T2 * S)));           /* at x = 1 */
     pix_real E0 = a0 + b0, E3 = a0 - b0, E1 = a1 + b1, E2 = a1 - b1;
@@ -1254,6 +1254,36 @@ __device__ __forceinline__ int green_fix(const ChromaTerms &t, int Y) {
 __device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
 
 /*
+ * The same terms from two 256-entry LDS tables (k_pixel builds them once per work-group):
+ * entry c of the Cb table (is_cr = false) / the Cr table = { G word, d | flag << 16 }
+ *   d       floor(1.772 (c - 128)) resp. floor(1.402 (c - 128)), the multiply-shift floors above
+ *   G word  n = -34414 (c - 128) resp. -71414 (c - 128), split n = q * 100000 + rem (0 <= rem < 100000),
+ *           as q * 2^20 + rem; the Cr table adds 2^20 - 100000 to its rem.  The sum of the two G words
+ *           then carries into bit 20 exactly when rem_b + rem_r >= 100000 (and never further), so
+ *           floor((n_b + n_r) / 100000) = (G_b + G_r) >> 20, arithmetic: two instructions for dg
+ *   flag    c == 28 (Cb) resp. c == 228 (Cr): both set = the exceptional pair of chroma_terms
+ */
+__device__ __forceinline__ uint2 ctab_entry(uint32_t c, bool is_cr) {
+    const int v = (int)c - 128;
+    const int d = is_cr ? (__mul24(v, 91882) >> 16) : (__mul24(v, 116130) >> 16);
+    const int n = is_cr ? -71414 * v : -34414 * v;
+    const int q = (n + 100000 * 128) / 100000 - 128;            /* floor(n / 100000) */
+    const uint32_t rem = (uint32_t)(n - q * 100000);
+    const uint32_t g = ((uint32_t)q << 20) + rem + (is_cr ? (1u << 20) - 100000u : 0u);
+    const uint32_t flag = (is_cr ? c == 228u : c == 28u) ? 0x10000u : 0u;
+    return make_uint2(g, ((uint32_t)d & 0xFFFFu) | flag);
+}
+#define JD_CTAB_CR 256u   /* the Cr table follows the Cb table */
+__device__ __forceinline__ ChromaTerms chroma_lookup(const uint2 *ctab, uint32_t cbv, uint32_t crv) {
+    const uint2 b = ctab[cbv], r = ctab[JD_CTAB_CR + crv];
+    ChromaTerms t;
+    t.dr = (int)r.y; t.db = (int)b.y;            /* low halves; the users take 16 bits */
+    t.dg = (int)(b.x + r.x) >> 20;
+    t.exc = (b.y & r.y) >> 16;
+    return t;
+}
+
+/*
  * 4 pixels -> their 12 output bytes, two pixels per instruction.  Px4: per channel the bytes of
  * pixels (0, 2) and of pixels (1, 3), each pair in the low two bytes of a register -- what
  * v_sat_pk_u8_i16 leaves when it clamps two 16-bit sums to 0..255 and packs them, which is the
@@ -1269,27 +1299,17 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
-/* y4: the luma bytes of the 4 pixels; cbv / crv: their chroma (nterms == 2: pixels 0, 1 share
- * entry 0 and pixels 2, 3 entry 2) */
-template <bool OUT_YCBCR>
-__device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const uint32_t crv[4], int nterms) {
+/* y4: the luma bytes of the 4 pixels; cbv / crv: their chroma */
+__device__ __forceinline__ Px4 ycc4(uint32_t y4, const uint32_t cbv[4], const uint32_t crv[4]) {
     Px4 r;
-    if (OUT_YCBCR) {
-        r.c02[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0200u); r.c13[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0301u);
-        r.c02[1] = cbv[0] | (cbv[2] << 8); r.c13[1] = cbv[1] | (cbv[3] << 8);
-        r.c02[2] = crv[0] | (crv[2] << 8); r.c13[2] = crv[1] | (crv[3] << 8);
-        return r;
-    }
-    ChromaTerms ct[4];
-    ct[0] = chroma_terms((int)cbv[0], (int)crv[0]);
-    ct[2] = chroma_terms((int)cbv[2], (int)crv[2]);
-    if (nterms == 4) {
-        ct[1] = chroma_terms((int)cbv[1], (int)crv[1]);
-        ct[3] = chroma_terms((int)cbv[3], (int)crv[3]);
-    } else {
-        ct[1] = ct[0];
-        ct[3] = ct[2];
-    }
+    r.c02[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0200u); r.c13[0] = __builtin_amdgcn_perm(0u, y4, 0x0C0C0301u);
+    r.c02[1] = cbv[0] | (cbv[2] << 8); r.c13[1] = cbv[1] | (cbv[3] << 8);
+    r.c02[2] = crv[0] | (crv[2] << 8); r.c13[2] = crv[1] | (crv[3] << 8);
+    return r;
+}
+/* ct: the chroma terms of the 4 pixels (with chroma shared by two columns, ct[1] = ct[0], ct[3] = ct[2]) */
+__device__ __forceinline__ Px4 rgb4(uint32_t y4, const ChromaTerms ct[4]) {
+    Px4 r;
     const uint32_t y02 = y4 & 0x00FF00FFu, y13 = (y4 >> 8) & 0x00FF00FFu;   /* two 16-bit lanes each */
     uint32_t s02[3] = {pk_add16(y02, pack16(ct[0].dr, ct[2].dr)), pk_add16(y02, pack16(ct[0].dg, ct[2].dg)),
                        pk_add16(y02, pack16(ct[0].db, ct[2].db))};
@@ -1317,15 +1337,17 @@ __device__ __forceinline__ Px4 colour4(uint32_t y4, const uint32_t cbv[4], const
 #define JD_FMT_4 1u       /* 4 interleaved bytes, the fourth 255 */
 #define JD_FMT_PLANAR 2u  /* three planes of width*height bytes */
 template <uint32_t FMT>
-__device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t at, const Px4 &v, bool aligned,
+__device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t at, const Px4 &v, bool aligned,
                                           uint32_t npx) {
-    /* at = y * width + x (< 2^32: both are 16-bit), plane = width * height.  v_perm_b32 picks the
-     * output bytes: selector 0..3 = bytes of the second operand, 4..7 = of the first, 0x0D = 0xFF */
+    /* rows: the image's output at the first pixel row of this MCU row (wave-uniform: a scalar base);
+     * at = r * width + x within it (< 2^22: r < 32, width < 2^16), so every address is the scalar
+     * base plus a 32-bit lane offset; plane = width * height.  v_perm_b32 picks the output bytes:
+     * selector 0..3 = bytes of the second operand, 4..7 = of the first, 0x0D = 0xFF */
     if (FMT == JD_FMT_PLANAR) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t w = __builtin_amdgcn_perm(v.c13[c], v.c02[c], 0x05010400u);   /* pixels 0, 1, 2, 3 */
-            uint8_t *dst = out + c * plane + at;
+            uint8_t *dst = rows + c * plane + at;
             if (aligned) *reinterpret_cast<uint32_t *>(dst) = w;       /* W % 4 == 0 */
             else
                 for (uint32_t i = 0; i < npx; ++i) dst[i] = (uint8_t)(w >> (8 * i));
@@ -1339,7 +1361,7 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t a
         /* 16 bytes per lane, always aligned (x is a multiple of 4, images start on 256 bytes) */
         const uint32_t p[4] = {__builtin_amdgcn_perm(br, rg02, 0x0D040200u), __builtin_amdgcn_perm(gb13, br, 0x0D060402u),
                                __builtin_amdgcn_perm(br, rg02, 0x0D050301u), __builtin_amdgcn_perm(gb13, br, 0x0D070503u)};
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 4);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(rows + at * 4u);
         if (npx == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
         else
             for (uint32_t i = 0; i < npx; ++i) dst[i] = p[i];
@@ -1347,11 +1369,12 @@ __device__ __forceinline__ void store_px4(uint8_t *out, size_t plane, uint32_t a
         const uint32_t w[3] = {__builtin_amdgcn_perm(br, rg02, 0x06040200u),      /* R0 G0 B0 R1 */
                                __builtin_amdgcn_perm(rg02, gb13, 0x07050200u),    /* G1 B1 R2 G2 */
                                __builtin_amdgcn_perm(gb13, br, 0x07050301u)};     /* B2 R3 G3 B3 */
+        uint8_t *dst = rows + at * 3u;
         if (aligned) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)at * 3);
-            dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
+            uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+            d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];
         } else {
-            for (uint32_t i = 0; i < npx * 3; ++i) out[(size_t)at * 3 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+            for (uint32_t i = 0; i < npx * 3; ++i) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
     }
 }
@@ -1400,6 +1423,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
     __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
     __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
+    __shared__ uint2 s_ctab[OUT_YCBCR ? 1 : 512]; /* colour transform terms per Cb / Cr value (ctab_entry) */
 
     const jd_pix_wg wg = wgs[blockIdx.x];
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
@@ -1420,6 +1444,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                       ((uint32_t)im.comp_H[c] << 8) | ((plane >> 6) << 12);
     }
     if (tid < 8 * JD_MAX_BPM) s_jmap[tid] = (uint16_t)((tid / bpm) | ((tid % bpm) << 8));
+    if (!OUT_YCBCR)
+        for (uint32_t i = tid; i < 512; i += 64 * JD_PIX_WAVES) s_ctab[i] = ctab_entry(i & 255u, i >= JD_CTAB_CR);
     const uint32_t mcu_first = wg.mcu_col0 + wave * sub_mcus;          /* first MCU column of this wave */
     const uint32_t my_mcus = mcu_first < im.mcus_x ? min(sub_mcus, im.mcus_x - mcu_first) : 0u;
     const uint32_t nblk = my_mcus * bpm;
@@ -1454,6 +1480,19 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
      * out the HBM latency, computed and left spent a third of its life in that wait. */
+    /* where the lane's row of unit j goes in the sample tile, and its row of the quantisation table */
+    auto unit_geom = [&](uint32_t j, uint32_t &toff, uint32_t &qoff) {
+        const uint32_t jm = s_jmap[j], m = jm & 255u, meta = s_meta[jm >> 8];
+        const uint32_t row = ((meta >> 6) & 3u) * 8u + l;
+        const uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
+        toff = (meta >> 12) * 64u + row * PIX_ROW + colpx;
+        qoff = ((meta >> 2) & 3u) * 64u + l * 8u;
+    };
+    /* the first 24 units of a row (all of them in most layouts) sit in the same places in every MCU row */
+    uint32_t g_toff[3] = {0, 0, 0}, g_qoff[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (8u * i + slot < nblk) unit_geom(8u * i + slot, g_toff[i], g_qoff[i]);
     uint4 ahead[3]; /* single buffer: chunk i of the next row is loaded as soon as step i has used it */
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1475,11 +1514,11 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                 } else if (act && mrow + 1 < row_end) {
                     ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
                 }
-                uint32_t m = 0, b = 0, meta = 0;
+                uint32_t toff = g_toff[i], qoff = g_qoff[i];
                 pix_real col[8], t[8];
                 if (act) {
-                    const uint32_t jm = s_jmap[j]; m = jm & 255u; b = jm >> 8; meta = s_meta[b];
-                    uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[(meta >> 2) & 3u][l * 8]);
+                    if (r0) unit_geom(j, toff, qoff);
+                    uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[0][0] + qoff);
                     const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1503,9 +1542,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     const uint32_t p45 = sat_pk_u8(cvt_pk_i16(to_int128(t[4]), to_int128(t[5])));
                     const uint32_t p67 = sat_pk_u8(cvt_pk_i16(to_int128(t[6]), to_int128(t[7])));
                     const uint32_t w0 = p01 | (p23 << 16), w1 = p45 | (p67 << 16);
-                    uint32_t row = ((meta >> 6) & 3u) * 8u + l;
-                    uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
-                    *reinterpret_cast<uint2 *>(&tile[(meta >> 12) * 64u + row * PIX_ROW + colpx]) = make_uint2(w0, w1);
+                    *reinterpret_cast<uint2 *>(&tile[toff]) = make_uint2(w0, w1);
                 }
                 WAVE_SYNC();
             }
@@ -1514,6 +1551,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         /* ---- phase 2 ---- */
         const uint32_t y0 = mrow * 8u * maxV;
         const uint32_t rows = min(8u * maxV, H - y0);
+        /* output of pixel row y0 (wave-uniform): plane 0 of the planar layout, else the interleaved pixels */
+        uint8_t *const orow = out + (size_t)y0 * W * (FMT == JD_FMT_PLANAR ? 1u : FMT == JD_FMT_4 ? 4u : 3u);
         if (draws) {
             /* 24-bit multiplies for the row offsets and the pixel index (rows, widths < 2^16): a
              * full 32-bit or 64-bit multiply costs as much as four plain instructions */
@@ -1543,14 +1582,24 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { cbv[i] = (cb4 >> (8 * i)) & 255u; crv[i] = (cr4 >> (8 * i)) & 255u; }
                     }
+                    ChromaTerms ct[4];
+                    if (!OUT_YCBCR && !GRAY) {
+                        ct[0] = chroma_lookup(s_ctab, cbv[0], crv[0]);
+                        ct[2] = chroma_lookup(s_ctab, cbv[2], crv[2]);
+                        if (HSH) { ct[1] = ct[0]; ct[3] = ct[2]; }
+                        else { ct[1] = chroma_lookup(s_ctab, cbv[1], crv[1]); ct[3] = chroma_lookup(s_ctab, cbv[3], crv[3]); }
+                    } else if (!OUT_YCBCR) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ct[i] = ChromaTerms{0, 0, 0, 0u};   /* neutral chroma: R = G = B = Y */
+                    }
                     const uint32_t offY = ((offC - CB * g) << VSH) + 4u * g;   /* luma row (rp << VSH), column 4g */
 #pragma unroll
                     for (uint32_t dy = 0; dy < (1u << VSH); ++dy) {
                         uint32_t r = (rp << VSH) + dy;
                         if (r < rows) {
                             uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[offY + dy * PIX_ROW]);
-                            Px4 v = colour4<OUT_YCBCR>(y4, cbv, crv, HSH ? 2 : 4);
-                            store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
+                            Px4 v = OUT_YCBCR ? ycc4(y4, cbv, crv) : rgb4(y4, ct);
+                            store_px4<FMT>(orow, plane, __umul24(r, W) + x, v, aligned, npx);
                         }
                     }
                 }
@@ -1575,8 +1624,15 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         }
                     }
                     uint32_t y4 = sm[0][0] | (sm[0][1] << 8) | (sm[0][2] << 16) | (sm[0][3] << 24);
-                    Px4 v = colour4<OUT_YCBCR>(y4, sm[1], sm[2], 4);
-                    store_px4<FMT>(out, plane, __umul24(y0 + r, W) + x, v, aligned, npx);
+                    Px4 v;
+                    if (OUT_YCBCR) v = ycc4(y4, sm[1], sm[2]);
+                    else {
+                        ChromaTerms ct[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ct[i] = chroma_lookup(s_ctab, sm[1][i], sm[2][i]);
+                        v = rgb4(y4, ct);
+                    }
+                    store_px4<FMT>(orow, plane, __umul24(r, W) + x, v, aligned, npx);
                 }
             }
         }
