@@ -404,7 +404,9 @@ template <bool LIGHT>
 __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top) {
     const uint32_t off = isdc ? desc.dc_off : desc.ac_off;
     /* read sign-extended: link entries (bit 15) are the negative ones, no mask needed to tell */
-    const int se = *reinterpret_cast<const int16_t *>(T.lut + off + ((top >> (32 - JD_LUT_BITS)) << 1));
+    /* v_bfe_u32 + v_lshl_add_u32 (the builtin keeps the compiler from folding the two shifts into
+     * shift + mask + add) */
+    const int se = *reinterpret_cast<const int16_t *>(T.lut + (__builtin_amdgcn_ubfe(top, 32 - JD_LUT_BITS, JD_LUT_BITS) * 2u + off));
     uint32_t e = (uint32_t)se;
     if (__builtin_expect(se < 0, 0)) {
         const uint32_t first = e & 0xFFFu;
@@ -463,18 +465,25 @@ __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
 struct BitReader {
     const char *base;          /* the image's clean stream (uniform: a scalar base + 32-bit lane offsets; the plan keeps a
                                   stream below 4 GiB) */
-    uint32_t own, dnx;         /* dword index of word 0 of this segment; distance to that of the next */
+    uint32_t b_own, b_next;    /* byte offset of word 0 of this segment; of the next one, biased (word_offset) */
     uint32_t w0, w1, w2;       /* window (byte-swapped to native order) */
     int r;                     /* unread bits of w0, 0..31 */
     uint32_t s;                /* window shifts since the last refill, 0..2 */
     uint32_t qa, qb;           /* the two words behind the window (raw, big-endian) */
     uint32_t c;                /* index of the word in qa */
 
+    /* byte offset of word w: 16-byte pieces are 1024 bytes apart, so word w sits at
+     * 4 w + 1008 (w >> 2) from word 0 of its segment (5 instructions, the mask-and-or form took 8).
+     * For w >= JD_SEG_WORDS the same expression runs on from the NEXT segment's word 0 when it starts
+     * at b_next = that word's offset - (4 + 1008 / 4) JD_SEG_WORDS. */
+    __device__ __forceinline__ uint32_t word_offset(uint32_t w) const {
+        const uint32_t sel = w >= JD_SEG_WORDS ? b_next : b_own;
+        return __umul24(w >> 2, 1008u) + sel + (w << 2);
+    }
     /* raw (big-endian) word w of this segment, w >= JD_SEG_WORDS: of the next; the byte swap is
      * done when the word is USED, so that the load stays in flight instead of being waited for */
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
-        const uint32_t o = ((w & (JD_SEG_WORDS - 4u)) << 6) | (w & 3u);     /* 16-byte pieces are 256 dwords apart */
-        return *reinterpret_cast<const uint32_t *>(base + ((own + o + (w >= JD_SEG_WORDS ? dnx : 0u)) << 2));
+        return *reinterpret_cast<const uint32_t *>(base + word_offset(w));
     }
     /* start at bit p of the segment */
     __device__ __forceinline__ void init(uint32_t p) {
@@ -512,8 +521,9 @@ struct BitReader {
 __device__ __forceinline__ BitReader make_reader(const uint8_t *clean_img, uint32_t seg, uint32_t n_segs) {
     BitReader r;
     r.base = reinterpret_cast<const char *>(clean_img);
-    r.own = (uint32_t)clean_word_index(seg, 0);
-    r.dnx = (seg + 1 < n_segs) ? (uint32_t)clean_word_index(seg + 1, 0) - r.own : 0u;
+    r.b_own = (uint32_t)clean_word_index(seg, 0) << 2;
+    /* no next segment: the words past the end are never used; keep the loads inside the buffer */
+    r.b_next = ((seg + 1 < n_segs) ? (uint32_t)clean_word_index(seg + 1, 0) << 2 : r.b_own) - (4u + 252u) * JD_SEG_WORDS;
     return r;
 }
 
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
      * for those loads BEFORE the loop.  gfx9 counts loads and stores in one in-order counter: a
      * wait for a pre-loop load placed inside the loop is a wait for all but the newest few memory
      * operations, i.e. for the flush stores of the previous iteration, in every iteration. */
-    asm volatile("" ::"v"(avail), "v"(valid), "v"(limit), "v"(B), "v"(p), "v"(k), "v"(b), "v"(R.own), "v"(R.dnx), "v"(cbase), "v"(pr0), "v"(pr1), "v"(pr2));
+    asm volatile("" ::"v"(avail), "v"(valid), "v"(limit), "v"(B), "v"(p), "v"(k), "v"(b), "v"(R.b_own), "v"(R.b_next), "v"(cbase), "v"(pr0), "v"(pr1), "v"(pr2));
     while (__any(active)) {
         bool finished = false; /* an OWNED unit was completed in this iteration */
         int fB = 0;            /* ... and this is its index */

@@ -117,22 +117,47 @@ def _flat_block_jpeg(pkg, oracle, mcus, w, h):
         return out
     dc = [codes(d.huff[0][0]), codes(d.huff[0][1]), codes(d.huff[0][1])]
     eob = [codes(d.huff[1][0])[0], codes(d.huff[1][1])[0], codes(d.huff[1][1])[0]]
-    acc, nbits, pred = 0, 0, [0, 0, 0]
+    vals, lens, pred = [], [], [0, 0, 0]
     for triple in mcus:
         for c, v in enumerate(triple):
             coef = (int(v) - 128) * 8            # flat unit: sample = DC / 8 + 128 (T[0][x]^2 / 4 = 1/8)
             diff, pred[c] = coef - pred[c], coef
             cat = abs(diff).bit_length()
             code, ln = dc[c][cat]
-            acc, nbits = (acc << ln) | code, nbits + ln
-            if cat:
-                acc, nbits = (acc << cat) | (diff if diff > 0 else diff + (1 << cat) - 1), nbits + cat
-            code, ln = eob[c]
-            acc, nbits = (acc << ln) | code, nbits + ln
-    pad = -nbits % 8
-    acc, nbits = (acc << pad) | ((1 << pad) - 1), nbits + pad
-    scan = acc.to_bytes(nbits // 8, "big").replace(b"\xff", b"\xff\x00")
+            vals.append((code << cat) | ((diff if diff > 0 else diff + (1 << cat) - 1) if cat else 0))
+            lens.append(ln + cat)
+            vals.append(eob[c][0])
+            lens.append(eob[c][1])
+    vals, lens = np.array(vals, np.int64), np.array(lens, np.int64)
+    start = np.cumsum(lens) - lens
+    nbits = int(lens.sum())
+    bits = np.ones((nbits + 7) // 8 * 8, np.uint8)           # the padding bits are ones
+    bits[:nbits] = 0
+    for b in range(int(lens.max())):                         # bit b (from the LSB) of every code that has one
+        m = lens > b
+        bits[start[m] + lens[m] - 1 - b] = (vals[m] >> b) & 1
+    scan = np.packbits(bits).tobytes().replace(b"\xff", b"\xff\x00")
     return hdr + scan + b"\xff\xd9"
+
+
+def test_every_chroma_pair_through_the_pixel_kernel(pkg, dec, oracle):
+    """k_pixel takes its colour terms from two LDS tables (one entry per Cb value, one per Cr value,
+    combined by an add and a shift).  Every one of the 65536 (Cb, Cr) pairs, at a luma inside and one
+    outside the exceptional range of src/image.c:46, in front of that stage == the oracle's
+    image_ycbcr_to_rgb (itself pinned over all 2^24 triples)."""
+    cb, cr = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    triples = [(y, int(b), int(r)) for y in (100, 201) for b, r in zip(cb.ravel(), cr.ravel())]
+    w, h = 8 * 256, 8 * 512
+    f = _flat_block_jpeg(pkg, oracle, triples, w, h)
+    rc, ycc = oracle.ycbcr(f)
+    assert rc == 0
+    got = ycc[::8, ::8].reshape(-1, 3)
+    assert np.array_equal(got, np.array(triples, np.uint8))   # the stream holds what was asked for
+    want = oracle.to_rgb(ycc)
+    for flags, view in ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0))):
+        out = dec.decode([f], flags)
+        assert out.status(0) == 0
+        assert np.array_equal(view(out.pixels(0)), want)
 
 
 def test_exceptional_chroma_pair_through_the_pixel_kernel(pkg, dec, oracle):
