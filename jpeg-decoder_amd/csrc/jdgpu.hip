@@ -462,6 +462,11 @@ __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
 #ifndef JD_RSTEPS
 #define JD_RSTEPS 2
 #endif
+/* AC symbol steps per iteration of the light decodes, after the one DC step.  Odd: DC step + AC
+ * steps pair up, a refill after each pair. */
+#ifndef JD_ASTEPS
+#define JD_ASTEPS 3
+#endif
 struct BitReader {
     const char *base;          /* the image's clean stream (uniform: a scalar base + 32-bit lane offsets; the plan keeps a
                                   stream below 4 GiB) */
@@ -569,29 +574,41 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
         const uint32_t mark = (c + 1u) * JD_CP_BITS;
         const uint32_t lim = c < JD_CP ? min(valid, mark) : valid;
         while (p < lim) {
+            /* one step for any symbol: the lanes at the start of a data unit take their DC symbol here
+             * (the difference, src/decoding.c:44, goes to the sum of the unit's component) */
+            {
+                const bool isdc = k == 0u;
+                const uint32_t top = R.top();
+                const uint32_t e = lookup_entry<true>(T, tb, isdc, top);
+                fl |= e;
+                const uint32_t tot = e & 31u;
+                int d = extend_at(top, tot, (e >> 8) & 15u);
+                d = isdc ? d : 0;
+                dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
+                p += tot;
+                k = isdc ? 1u : k + ((e >> 5) & 127u);
+                R.consume(tot);
+                const bool end = k >= 64u;
+                k = end ? 0u : k; n += end ? 1 : 0; b = end ? tb.nb : b;
+            }
+            /* JD_ASTEPS AC symbols of the lanes inside a unit; a lane whose unit ends waits for the
+             * DC step of the next iteration */
 #pragma unroll
-            for (int st = 0; st < JD_RSTEPS; ++st) {
-                if (st == 0 || p < lim) {
-                    const bool isdc = k == 0;
+            for (int st = 0; st < JD_ASTEPS; ++st) {
+                if (k != 0u && p < lim) {
                     const uint32_t top = R.top();
-                    const uint32_t e = lookup_entry<true>(T, tb, isdc, top);
+                    const uint32_t e = lookup_entry<true>(T, tb, false, top);
                     fl |= e;
                     const uint32_t tot = e & 31u;
-                    /* DC difference (src/decoding.c:44), added to the sum of the unit's component */
-                    int d = extend_at(top, tot, (e >> 8) & 15u);
-                    d = isdc ? d : 0;
-                    dc0 = mad24(d, tb.e0, dc0); dc1 = mad24(d, tb.e1, dc1); dc2 = mad24(d, tb.e2, dc2);
                     p += tot;
-                    k = isdc ? 1u : k + ((e >> 5) & 127u);
+                    k += (e >> 5) & 127u;
                     R.consume(tot);
-                    /* end of the data unit, branch-free; the descriptor is re-read in every step so
-                     * that no divergent merge copies it around */
-                    const bool end = k >= 64u;
+                    const bool end = k >= 64u;   /* end of the data unit, branch-free */
                     k = end ? 0u : k; n += end ? 1 : 0; b = end ? tb.nb : b;
                 }
-                tb = T.blk[b];
+                if ((st & 1) == 0) R.refill();   /* after every second symbol step, all lanes */
             }
-            R.refill();
+            tb = T.blk[b]; /* once per iteration, all lanes: no divergent merge copies the descriptor around */
         }
         if (c < JD_CP && !matched) {
             if (p >= mark) {
