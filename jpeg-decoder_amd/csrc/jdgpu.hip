@@ -1076,9 +1076,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
         int fB = 0;            /* ... and this is its index */
 #pragma unroll
         for (int s = 0; s < JD_WSTEPS; ++s) {
-            if (active && !finished) {
+            /* the first step takes any symbol, the others AC symbols only (no predictors, no table
+             * select): a lane that completes a unit it owns pauses until the flush anyway, so only the
+             * lane that ends the unit it started in the middle of loses a step to this */
+            if (active && !finished && (s == 0 || k != 0u)) {
                 const uint32_t top = R.top();
-                const bool isdc = (k == 0);
+                const bool isdc = s == 0 && k == 0u;
                 const uint32_t e = lookup_entry<false>(T, tb, isdc, top);
                 const uint32_t len = (e & 15u) + 1u, size = (e >> 4) & 15u, kinc = (e >> 8) & 127u;
                 const uint32_t tot = len + size;
@@ -1116,8 +1119,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 B += end ? 1 : 0; own = own || end; k = end ? 0u : k; b = end ? nb : b;
                 active = ok && (k != 0 || p < valid) && B < limit;
             }
-            tb = s_blk[b]; /* every step, all lanes: no divergent merge copies the descriptor around */
         }
+        tb = s_blk[b]; /* once per iteration, all lanes: no divergent merge copies the descriptor around */
         R.refill(); /* all lanes, outside the divergent steps */
         /* ---- flush the units completed in this iteration (wave-synchronous) ---- */
         uint64_t fm = __ballot(finished);
