@@ -1267,6 +1267,24 @@ __device__ __forceinline__ void idct8(const pix_real in[8], pix_real out[8]) {
     out[3] = E3 + O3; out[4] = E3 - O3;
 }
 
+/* The same for in[4..7] == 0: the terms left out are exact zeros, so the result is bit-identical
+ * to idct8 on such input (23 instead of 35 operations). */
+template <int QUARTER>
+__device__ __forceinline__ void idct8_low(const pix_real in[4], pix_real out[8]) {
+    constexpr pix_real S = QUARTER ? 0.25 : 1.0;
+    const pix_real a = in[0] * (pix_real)(T0 * S);
+    const pix_real b0 = in[2] * (pix_real)(T2 * S), b1 = in[2] * (pix_real)(T6 * S);
+    const pix_real E0 = a + b0, E3 = a - b0, E1 = a + b1, E2 = a - b1;
+    const pix_real O0 = fma(in[1], (pix_real)(T1 * S), in[3] * (pix_real)(T3 * S));
+    const pix_real O1 = fma(in[1], (pix_real)(T3 * S), in[3] * (pix_real)(-T7 * S));
+    const pix_real O2 = fma(in[1], (pix_real)(T5 * S), in[3] * (pix_real)(-T1 * S));
+    const pix_real O3 = fma(in[1], (pix_real)(T7 * S), in[3] * (pix_real)(-T5 * S));
+    out[0] = E0 + O0; out[7] = E0 - O0;
+    out[1] = E1 + O1; out[6] = E1 - O1;
+    out[2] = E2 + O2; out[5] = E2 - O2;
+    out[3] = E3 + O3; out[4] = E3 - O3;
+}
+
 /* src/decoding.c:99: clamp(lround(v) + 128, 0, 255).  Adding 1.5 * 2^52 + 128 to v leaves
  * RN(v) + 128 in the low mantissa word (|v| << 2^31): round-to-nearest, which equals lround
  * except on exact ties -- and a sum of products with the six-decimal table is never an exact
@@ -1502,7 +1520,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
      * the data units it never reached hold whatever the (recycled) coefficient buffer held */
     if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
     const jd_image &im = imgs[wg.img];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* scalar: so is everything derived from it */
     /* one instantiation per pixel layout: the common ones get their geometry as constants */
     const uint32_t maxH = FAST ? 1u << HSH : im.maxH;
     const uint32_t maxV = FAST ? 1u << VSH : im.maxV;
@@ -1515,12 +1534,25 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
                       ((uint32_t)im.comp_H[c] << 8) | ((plane >> 6) << 12);
     }
-    if (tid < 8 * JD_MAX_BPM) s_jmap[tid] = (uint16_t)((tid / bpm) | ((tid % bpm) << 8));
+    if (tid < 8 * JD_MAX_BPM) {
+        /* order in which a wave takes the data units of its part of an MCU row, 8 at a time.  Generic:
+         * as stored.  The layouts with an instantiation: all luma units first, then Cb, then Cr, so that
+         * a group of 8 is of one kind -- chroma units seldom hold a coefficient beyond the low 4 x 4,
+         * and a group in which none does takes the short transform (idct8_low) */
+        uint32_t m = tid / bpm, b = tid % bpm;
+        if (FAST && !GRAY) {
+            const uint32_t nY = bpm - 2u, j2 = tid - sub_mcus * nY;
+            if (tid < sub_mcus * nY) { m = tid / nY; b = tid % nY; }
+            else { m = j2 % sub_mcus; b = nY + j2 / sub_mcus; }
+        }
+        s_jmap[tid] = (uint16_t)(m | (b << 8));
+    }
     if (!OUT_YCBCR)
         for (uint32_t i = tid; i < 512; i += 64 * JD_PIX_WAVES) s_ctab[i] = ctab_entry(i & 255u, i >= JD_CTAB_CR);
     const uint32_t mcu_first = wg.mcu_col0 + wave * sub_mcus;          /* first MCU column of this wave */
     const uint32_t my_mcus = mcu_first < im.mcus_x ? min(sub_mcus, im.mcus_x - mcu_first) : 0u;
     const uint32_t nblk = my_mcus * bpm;
+    const uint32_t ntot = FAST ? sub_mcus * bpm : nblk;   /* entries of s_jmap to walk; a narrow last part skips those of absent MCUs */
 
     /* ---- phase 1 ---- */
     const uint32_t l = lane & 7u, slot = lane >> 3;
@@ -1537,8 +1569,9 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const uint32_t row_end = min((uint32_t)wg.mcu_row + pix_rows, im.mcus_y);
     /* the wave's data units of one MCU row are consecutive in the coefficient buffer; lane: its
      * 16-byte column of unit `slot` */
-    const size_t row_stride = (size_t)im.mcus_x * bpm * 64;
-    const int16_t *cbase = coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64 + l * 8;
+    const size_t row_stride = (size_t)im.mcus_x * bpm * 128;   /* bytes */
+    /* coefficients of the wave's part of the MCU row (wave-uniform: a scalar base, 32-bit lane offsets) */
+    const char *cbase = reinterpret_cast<const char *>(coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64);
     const uint32_t W = im.width, H = im.height;
     const uint32_t x0 = mcu_first * 8u * maxH;
     const uint32_t g = lane & 15u, rq = lane >> 4, x = x0 + 4u * g;
@@ -1553,68 +1586,104 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
      * out the HBM latency, computed and left spent a third of its life in that wait. */
     /* where the lane's row of unit j goes in the sample tile, and its row of the quantisation table */
-    auto unit_geom = [&](uint32_t j, uint32_t &toff, uint32_t &qoff) {
-        const uint32_t jm = s_jmap[j], m = jm & 255u, meta = s_meta[jm >> 8];
+    auto unit_geom = [&](uint32_t j, uint32_t &toff, uint32_t &qoff, uint32_t &uoff) -> bool {
+        const uint32_t jm = s_jmap[j], m = jm & 255u, b = jm >> 8, meta = s_meta[b];
         const uint32_t row = ((meta >> 6) & 3u) * 8u + l;
         const uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
         toff = (meta >> 12) * 64u + row * PIX_ROW + colpx;
         qoff = ((meta >> 2) & 3u) * 64u + l * 8u;
+        uoff = (m * bpm + b) * 128u + l * 16u;    /* byte offset of the lane's column in the row's coefficients */
+        return m < my_mcus;
+    };
+    /* src/decoding.c:99 for two samples at a time: RN(v) + 128 as integers (to_int128), saturated to
+     * 16 bits and then to 0..255 by the two packing instructions; the 8 samples of a row go to the tile */
+    auto put_row = [&](const pix_real t[8], uint32_t toff) {
+        const uint32_t p01 = sat_pk_u8(cvt_pk_i16(to_int128(t[0]), to_int128(t[1])));
+        const uint32_t p23 = sat_pk_u8(cvt_pk_i16(to_int128(t[2]), to_int128(t[3])));
+        const uint32_t p45 = sat_pk_u8(cvt_pk_i16(to_int128(t[4]), to_int128(t[5])));
+        const uint32_t p67 = sat_pk_u8(cvt_pk_i16(to_int128(t[6]), to_int128(t[7])));
+        *reinterpret_cast<uint2 *>(&tile[toff]) = make_uint2(p01 | (p23 << 16), p45 | (p67 << 16));
     };
     /* the first 24 units of a row (all of them in most layouts) sit in the same places in every MCU row */
-    uint32_t g_toff[3] = {0, 0, 0}, g_qoff[3] = {0, 0, 0};
+    uint32_t g_toff[3] = {0, 0, 0}, g_qoff[3] = {0, 0, 0}, g_uoff[3] = {0, 0, 0};
+    bool g_act[3] = {false, false, false}, g_any[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (8u * i + slot < nblk) unit_geom(8u * i + slot, g_toff[i], g_qoff[i]);
+    for (int i = 0; i < 3; ++i) {
+        if (8u * i + slot < ntot) g_act[i] = unit_geom(8u * i + slot, g_toff[i], g_qoff[i], g_uoff[i]);
+        g_any[i] = __any(g_act[i]);   /* wave-uniform: false for a group of units of MCUs beyond the image's edge */
+    }
+    const uint32_t hi4 = l >= 4u ? ~0u : 0u;
     uint4 ahead[3]; /* single buffer: chunk i of the next row is loaded as soon as step i has used it */
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const uint32_t j = 8u * i + slot;
         ahead[i] = make_uint4(0, 0, 0, 0);
-        if (j < nblk) ahead[i] = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+        if (g_act[i]) ahead[i] = *reinterpret_cast<const uint4 *>(cbase + g_uoff[i]);
     }
     for (uint32_t mrow = wg.mcu_row; mrow < row_end; ++mrow, cbase += row_stride) {
-        for (uint32_t r0 = 0; r0 < nblk; r0 += 24) {
+        for (uint32_t r0 = 0; r0 < ntot; r0 += 24) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const uint32_t j = r0 + 8u * i + slot;
-                if (r0 + 8u * i >= nblk) break; /* wave-uniform */
-                const bool act = j < nblk;
-                uint4 raw = ahead[i];
+                if (r0 + 8u * i >= ntot) break; /* wave-uniform */
+                bool act = g_act[i], any = g_any[i];
+                uint32_t toff = g_toff[i], qoff = g_qoff[i], uoff = g_uoff[i];
+                uint4 raw = ahead[i];   /* zero in a lane without a unit */
                 if (r0) { /* layouts with more than 24 units per wave and row: loaded in place */
                     raw = make_uint4(0, 0, 0, 0);
-                    if (act) raw = *reinterpret_cast<const uint4 *>(cbase + (size_t)j * 64);
+                    act = j < ntot && unit_geom(j, toff, qoff, uoff);
+                    any = __any(act);
+                    if (act) raw = *reinterpret_cast<const uint4 *>(cbase + uoff);
                 } else if (act && mrow + 1 < row_end) {
-                    ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + (size_t)j * 64);
+                    ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + uoff);
                 }
-                uint32_t toff = g_toff[i], qoff = g_qoff[i];
+                if (!any) continue; /* wave-uniform */
+                /* lane: column l of its unit = the coefficients of horizontal frequency l, vertical
+                 * frequency 0..7 in raw.x .. raw.w.  No lane of the wave has one at a frequency of 4 or
+                 * more in either direction (wave-uniform): both passes take half the terms */
+                const bool low = !__any((raw.z | raw.w | ((raw.x | raw.y) & hi4)) != 0u);
                 pix_real col[8], t[8];
-                if (act) {
-                    if (r0) unit_geom(j, toff, qoff);
-                    uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[0][0] + qoff);
-                    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                if (low) {
+                    if (act) {
+                        const uint2 qv = *reinterpret_cast<const uint2 *>(&s_q[0][0] + qoff);
+                        const uint32_t rw[2] = {raw.x, raw.y}, qw[2] = {qv.x, qv.y};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
-                        col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                        col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
+                        for (int q = 0; q < 2; ++q) {
+                            int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
+                            col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                            col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
+                        }
+                        idct8_low<0>(col, t);
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
                     }
-                    idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
+                    WAVE_SYNC();
+                    if (act) {
 #pragma unroll
-                    for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
-                }
-                WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
-                if (act) {
+                        for (int u = 0; u < 4; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
+                        idct8_low<1>(col, t);
+                        put_row(t, toff);
+                    }
+                } else {
+                    if (act) {
+                        const uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[0][0] + qoff);
+                        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
-                    idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
-                    /* src/decoding.c:99 for two samples at a time: RN(v) + 128 as integers (to_int128),
-                     * saturated to 16 bits and then to 0..255 by the two packing instructions */
-                    const uint32_t p01 = sat_pk_u8(cvt_pk_i16(to_int128(t[0]), to_int128(t[1])));
-                    const uint32_t p23 = sat_pk_u8(cvt_pk_i16(to_int128(t[2]), to_int128(t[3])));
-                    const uint32_t p45 = sat_pk_u8(cvt_pk_i16(to_int128(t[4]), to_int128(t[5])));
-                    const uint32_t p67 = sat_pk_u8(cvt_pk_i16(to_int128(t[6]), to_int128(t[7])));
-                    const uint32_t w0 = p01 | (p23 << 16), w1 = p45 | (p67 << 16);
-                    *reinterpret_cast<uint2 *>(&tile[toff]) = make_uint2(w0, w1);
+                        for (int q = 0; q < 4; ++q) {
+                            int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
+                            col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
+                            col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
+                        }
+                        idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
+                    }
+                    WAVE_SYNC(); /* the 8 lanes of a unit sit in one wave */
+                    if (act) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
+                        idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
+                        put_row(t, toff);
+                    }
                 }
                 WAVE_SYNC();
             }
