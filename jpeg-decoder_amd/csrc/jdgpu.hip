@@ -556,12 +556,23 @@ struct BitReader {
         const uint32_t a = __builtin_bswap32(qa), b = __builtin_bswap32(qb);
         w1 = s == 2u ? a : w1;                     /* two shifts left w1 = w2 = the old w2 */
         w2 = s == 2u ? b : (s == 1u ? a : w2);
-        c += s; s = 0;
+        c += s;
 #ifdef JD_ABL_L1LOAD   /* ablation: the loads stay, but always hit the same line */
         qa = word(c & 3u); qb = word((c + 1u) & 3u);
+#elif !defined(JD_EAGER_LOADS)
+        /* Only the lanes whose window moved load, and only the words they lack: an iteration consumes
+         * a dozen bits on average, and the per-CU vector memory path (TA / L1) is what k_huff_write
+         * runs into -- reloading both words in every iteration made 7 L2 read requests per load
+         * instruction, 44 % of that path's traffic.  The old qb moves up BEFORE the loads are issued,
+         * so nothing reads a register a load is in flight to until the next refill. */
+        const uint32_t oa = word_offset(c), ob = word_offset(c + 1u);
+        qa = s == 1u ? qb : qa;
+        if (s == 2u) qa = *reinterpret_cast<const uint32_t *>(base + oa);
+        if (s != 0u) qb = *reinterpret_cast<const uint32_t *>(base + ob);
 #else
         qa = word(c); qb = word(c + 1u);
 #endif
+        s = 0;
     }
 };
 
