@@ -1012,6 +1012,7 @@ __constant__ uint8_t c_zz_cm[64];
  * partial-line stores of a 4096 x 1080p batch cost 4.4 ms.)
  */
 #define WBUF_BYTES 128u
+#define JD_NARROW_UNIT 64u   /* bytes of a data unit in the coefficient buffer of a narrow image (a wide one: 128) */
 #define JD_WSTEPS JD_RSTEPS
 __device__ __forceinline__ uint32_t wbuf_key(uint32_t lane) {
     /* 16-byte chunks permuted by the lane number (XOR on the chunk index): both the lanes'
@@ -1111,11 +1112,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     bool own = (k == 0); /* does this lane own the data unit it is in? */
     int dcv = 0;         /* NARROW: DC value of the unit in progress */
     uint32_t ovf = 0;    /* NARROW: an AC value that does not fit (cannot happen when `wide` is complete) */
+    uint32_t ovf2 = 0;   /* NARROW: a DC value beyond 12 bits or a last AC coefficient beyond 4, seen by a flush lane */
     int16_t *const cbase = coef + (size_t)im.blk_off * 64;
     const uint32_t bkey = NARROW ? nbuf_key(lane) : wbuf_key(lane);
     /* flush roles: eighth of the unit (byte offset in the unit buffer, dword offset in the line) */
-    const uint32_t qsub = (wlane & 7u) * (UB / 8u), osub = (wlane & 7u) * 4u;
-    const uint32_t dcmask = (wlane & 7u) == 0u ? 0xFFFFu : 0u;
+    const uint32_t qsub = (wlane & 7u) * (UB / 8u), osub = (wlane & 7u) * (NARROW ? 2u : 4u);
+    const uint32_t dc_on = (wlane & 7u) == 0u ? ~0u : 0u, top_on = (wlane & 7u) == 7u ? ~0u : 0u;
+    const uint32_t dcmask = dc_on & 0xFFu, topmask = top_on & 0xFF000000u;
 
     /* a unit is decoded while it STARTED before the end of the segment */
     active = active && (k != 0 || p < valid) && B < limit;
@@ -1192,33 +1195,37 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
             for (uint32_t g = wlane >> 3; g < nf; g += 8) {   /* 8 lanes per unit: one 16-byte store each, a full line per unit */
                 const uint2 qe = s_q[wbase + g];
                 const uint32_t src = wbase + (qe.y & 63u), blk = qe.x;
-                uint4 v;
                 if (NARROW) {
+                    /* the unit leaves as 64 bytes (JD_NARROW_UNIT, see narrow_unit_load): int8
+                     * coefficients, the 12-bit DC value in byte 0 and the low nibble of byte 63, the
+                     * last AC coefficient in the high nibble of byte 63 */
                     uint2 *lp = reinterpret_cast<uint2 *>(s_buf + (qsub ^ nbuf_key(src)));
-                    const uint2 n8 = *lp;
+                    uint2 n8 = *lp;
                     *lp = make_uint2(0, 0);
-                    v = make_uint4(widen_pair(n8.x, 0x010C000Cu), widen_pair(n8.x, 0x030C020Cu), widen_pair(n8.y, 0x010C000Cu), widen_pair(n8.y, 0x030C020Cu));
-                    v.x = (v.x & ~dcmask) | ((qe.y >> 16) & dcmask);   /* v_bfi: the DC value, first piece only */
+                    const int dc = (int)qe.y >> 16;
+                    const int a63 = (int)n8.y >> 24;
+                    /* what does not fit (no valid stream of 8-bit samples has such a DC): the safety net below */
+                    ovf2 |= ((uint32_t)(dc + 2048) & ~4095u & dc_on) | ((uint32_t)(a63 + 8) & ~15u & top_on);
+                    n8.x = (n8.x & ~dcmask) | ((uint32_t)dc & dcmask);
+                    const uint32_t top = (((uint32_t)dc << 16) & 0x0F000000u) | ((n8.y << 4) & 0xF0000000u);
+                    n8.y = (n8.y & ~topmask) | (top & topmask);
+                    uint32_t *out = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cbase) + (size_t)blk * JD_NARROW_UNIT) + osub;
+#ifdef JD_ABL_NOSTORE   /* ablation: the stores go to one small region */
+                    out = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cbase) + (size_t)(blk & 1023u) * JD_NARROW_UNIT) + osub;
+#endif
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store((u2){n8.x, n8.y}, reinterpret_cast<u2 *>(out));
                 } else {
                     uint4 *lp = reinterpret_cast<uint4 *>(s_buf + (qsub ^ wbuf_key(src)));
-                    v = *lp;
+                    const uint4 v = *lp;
                     *lp = make_uint4(0, 0, 0, 0);
-                }
-                /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
-                uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64) + osub;
-#ifdef JD_ABL_NOSTORE   /* ablation: the stores go to one small region */
-                out = reinterpret_cast<uint32_t *>(cbase + (size_t)(blk & 1023u) * 64) + osub;
+                    /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
+                    uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64) + osub;
+#ifdef JD_ABL_NOSTORE
+                    out = reinterpret_cast<uint32_t *>(cbase + (size_t)(blk & 1023u) * 64) + osub;
 #endif
-#ifdef JD_ABL_NOSTORE2  /* ablation: one lane in 64 stores */
-                if (v.x == 0x12345678u)
-#endif
-                {
-#ifdef JD_ABL_PLAINSTORE
-                *reinterpret_cast<uint4 *>(out) = v;
-#else
-                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store((u4){v.x, v.y, v.z, v.w}, reinterpret_cast<u4 *>(out));
-#endif
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((u4){v.x, v.y, v.z, v.w}, reinterpret_cast<u4 *>(out));
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1228,7 +1235,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     }
     /* data ended before the interval's data units did */
     if (!flags && seg < n_segs && B < limit && is_last) flags |= JDGPU_IMG_EOF;
-    if (NARROW && (ovf & ~255u)) { /* safety net: mark the image wide and have the host run the pass again */
+    if (NARROW && ((ovf & ~255u) | ovf2)) { /* safety net: mark the image wide and have the host run the pass again */
         atomicOr(&wide[wg.img], 1u);
         flags |= JDGPU_IMG_UNSYNCED;
     }
@@ -1510,6 +1517,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                const int16_t *__restrict__ coef,
                                                uint8_t *__restrict__ pix,
                                                const uint32_t *__restrict__ status,
+                                               const uint32_t *__restrict__ wide,   /* per image: 0 = 64-byte units; null: none is */
                                                uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) pix_real s_tr[8 * JD_PIX_WAVES * TR_BLK];
     /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
@@ -1531,6 +1539,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
      * the data units it never reached hold whatever the (recycled) coefficient buffer held */
     if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
     const jd_image &im = imgs[wg.img];
+    const bool nar = wide != nullptr && wide[wg.img] == 0u;   /* the image's units are in the narrow form (k_huff_write) */
+    const uint32_t ub = nar ? JD_NARROW_UNIT : 128u;          /* bytes per unit */
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* scalar: so is everything derived from it */
     /* one instantiation per pixel layout: the common ones get their geometry as constants */
@@ -1580,9 +1590,11 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const uint32_t row_end = min((uint32_t)wg.mcu_row + pix_rows, im.mcus_y);
     /* the wave's data units of one MCU row are consecutive in the coefficient buffer; lane: its
      * 16-byte column of unit `slot` */
-    const size_t row_stride = (size_t)im.mcus_x * bpm * 128;   /* bytes */
-    /* coefficients of the wave's part of the MCU row (wave-uniform: a scalar base, 32-bit lane offsets) */
-    const char *cbase = reinterpret_cast<const char *>(coef + ((size_t)im.blk_off + ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm) * 64);
+    const size_t row_stride = (size_t)im.mcus_x * bpm * ub;   /* bytes */
+    /* coefficients of the wave's part of the MCU row (wave-uniform: a scalar base, 32-bit lane offsets);
+     * an image's units start at blk_off * 128 bytes in either form */
+    const char *cbase = reinterpret_cast<const char *>(coef + (size_t)im.blk_off * 64) +
+                        ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm * ub;
     const uint32_t W = im.width, H = im.height;
     const uint32_t x0 = mcu_first * 8u * maxH;
     const uint32_t g = lane & 15u, rq = lane >> 4, x = x0 + 4u * g;
@@ -1603,8 +1615,35 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         const uint32_t colpx = (m * ((meta >> 8) & 15u) + ((meta >> 4) & 3u)) * 8u;
         toff = (meta >> 12) * 64u + row * PIX_ROW + colpx;
         qoff = ((meta >> 2) & 3u) * 64u + l * 8u;
-        uoff = (m * bpm + b) * 128u + l * 16u;    /* byte offset of the lane's column in the row's coefficients */
+        uoff = (m * bpm + b) * ub + l * (ub >> 3);   /* byte offset of the lane's column in the row's coefficients */
         return m < my_mcus;
+    };
+    /* the lane's column of a unit: 8 int16 (raw.x .. raw.w) or, narrow, 8 int8 (raw.x, raw.y) */
+    auto load_col = [&](const char *p) -> uint4 {
+        if (nar) { const uint2 t = *reinterpret_cast<const uint2 *>(p); return make_uint4(t.x, t.y, 0u, 0u); }
+        return *reinterpret_cast<const uint4 *>(p);
+    };
+    /* quantised coefficients v0 .. v0 + N - 1 of the column times their table entries (src/decoding.c:46,65).
+     * Narrow: byte 0 of column 0 is the low byte of the 12-bit DC value, whose high nibble column 7
+     * holds in the low half of its last byte (the high half: the last AC coefficient); dc12 / a63 are
+     * those two values, put right before the call */
+    auto dequant = [&](const uint4 &raw, uint32_t qoff, pix_real *col, int n /* 4 or 8 */) {
+        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t qw[4];
+        if (n == 8) { const uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[0][0] + qoff); qw[0] = qv.x; qw[1] = qv.y; qw[2] = qv.z; qw[3] = qv.w; }
+        else { const uint2 qv = *reinterpret_cast<const uint2 *>(&s_q[0][0] + qoff); qw[0] = qv.x; qw[1] = qv.y; qw[2] = qw[3] = 0; }
+        if (nar) {   /* wave-uniform: a real branch, not a select per coefficient */
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < n) col[k] = (pix_real)__mul24((int)(int8_t)(rw[k >> 2] >> (8 * (k & 3))), (int)((qw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+            /* column 0 cannot hold 12 bits in a byte: its first product is made from raw.w */
+            col[0] = l == 0u ? (pix_real)__mul24((int)raw.w, (int)(qw[0] & 0xFFFFu)) : col[0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < n) col[k] = (pix_real)__mul24((int)(int16_t)(rw[k >> 1] >> (16 * (k & 1))), (int)((qw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+        }
     };
     /* src/decoding.c:99 for two samples at a time: RN(v) + 128 as integers (to_int128), saturated to
      * 16 bits and then to 0..255 by the two packing instructions; the 8 samples of a row go to the tile */
@@ -1628,7 +1667,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         ahead[i] = make_uint4(0, 0, 0, 0);
-        if (g_act[i]) ahead[i] = *reinterpret_cast<const uint4 *>(cbase + g_uoff[i]);
+        if (g_act[i]) ahead[i] = load_col(cbase + g_uoff[i]);
     }
     for (uint32_t mrow = wg.mcu_row; mrow < row_end; ++mrow, cbase += row_stride) {
         for (uint32_t r0 = 0; r0 < ntot; r0 += 24) {
@@ -1643,26 +1682,30 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     raw = make_uint4(0, 0, 0, 0);
                     act = j < ntot && unit_geom(j, toff, qoff, uoff);
                     any = __any(act);
-                    if (act) raw = *reinterpret_cast<const uint4 *>(cbase + uoff);
+                    if (act) raw = load_col(cbase + uoff);
                 } else if (act && mrow + 1 < row_end) {
-                    ahead[i] = *reinterpret_cast<const uint4 *>(cbase + row_stride + uoff);
+                    ahead[i] = load_col(cbase + row_stride + uoff);
                 }
                 if (!any) continue; /* wave-uniform */
                 /* lane: column l of its unit = the coefficients of horizontal frequency l, vertical
                  * frequency 0..7 in raw.x .. raw.w.  No lane of the wave has one at a frequency of 4 or
                  * more in either direction (wave-uniform): both passes take half the terms */
-                const bool low = !__any((raw.z | raw.w | ((raw.x | raw.y) & hi4)) != 0u);
+                if (nar) {
+                    /* put the two shared bytes right: column 7 gets its last coefficient as an int8 again,
+                     * column 0 its DC value in raw.z (bits 0..11 = byte 0 | nibble << 8, sign-extended below) */
+                    const uint32_t y7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.y, 0x107, 0xF, 0xF, true); /* row_shl:7: lane 8k <- lane 8k + 7 */
+                    const uint32_t fixed = (raw.y & 0x00FFFFFFu) | ((uint32_t)((int)raw.y >> 28) << 24);
+                    raw.y = l == 7u ? fixed : raw.y;
+                    const int dc12 = __builtin_amdgcn_sbfe((int)((raw.x & 0xFFu) | ((y7 >> 16) & 0xF00u)), 0, 12);
+                    /* column 0 cannot hold 12 bits in a byte: its first product is made here, from raw.w */
+                    raw.w = (uint32_t)dc12;
+                }
+                const bool low = nar ? !__any((raw.y | ((raw.x | raw.y) & hi4)) != 0u)
+                                     : !__any((raw.z | raw.w | ((raw.x | raw.y) & hi4)) != 0u);
                 pix_real col[8], t[8];
                 if (low) {
                     if (act) {
-                        const uint2 qv = *reinterpret_cast<const uint2 *>(&s_q[0][0] + qoff);
-                        const uint32_t rw[2] = {raw.x, raw.y}, qw[2] = {qv.x, qv.y};
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
-                            col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                            col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
-                        }
+                        dequant(raw, qoff, col, 4);
                         idct8_low<0>(col, t);
 #pragma unroll
                         for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
@@ -1676,14 +1719,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     }
                 } else {
                     if (act) {
-                        const uint4 qv = *reinterpret_cast<const uint4 *>(&s_q[0][0] + qoff);
-                        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            int lo = (int)(int16_t)(rw[q] & 0xFFFFu), hi = (int)(int16_t)(rw[q] >> 16);
-                            col[2 * q] = (pix_real)__mul24(lo, (int)(qw[q] & 0xFFFFu));     /* src/decoding.c:46,65 */
-                            col[2 * q + 1] = (pix_real)__mul24(hi, (int)(qw[q] >> 16));
-                        }
+                        dequant(raw, qoff, col, 8);
                         idct8<0>(col, t); /* vertical: t[y] = sum_v M[v][u] T[v][y] */
 #pragma unroll
                         for (int y = 0; y < 8; ++y) tr[((uint32_t)y ^ sx) * 8u + ((l + y) & 7u)] = t[y];
@@ -2139,12 +2175,19 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     return JDGPU_OK;
 }
 
+/* JDGPU_NARROW=0 (tests, A/B timing): every image takes the wide write kernel and 128-byte units */
+static bool narrow_units() {
+    static const bool narrow = [] { const char *e = getenv("JDGPU_NARROW"); return !e || atoi(e) != 0; }();
+    return narrow;
+}
+
 template <bool OUT_YCBCR, uint32_t MODE, uint32_t FMT>
 static void launch_pixel_mode(jdgpu_batch *b, hipStream_t st) {
     const uint32_t *f = b->plan.pwg_mode_first;
     if (f[MODE + 1] > f[MODE])
         hipLaunchKernelGGL((k_pixel<OUT_YCBCR, MODE, FMT>), dim3(f[MODE + 1] - f[MODE]), dim3(64 * JD_PIX_WAVES), 0, st,
-                           b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->d_status, b->plan.pix_rows);
+                           b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->d_status, narrow_units() ? b->d_wide : nullptr,
+                           b->plan.pix_rows);
 }
 template <bool OUT_YCBCR, uint32_t FMT>
 static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
@@ -2176,7 +2219,7 @@ static void launch_write(jdgpu_batch *b, hipStream_t st) {
     jd_plan &P = b->plan;
 #define WRITE_ARGS b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, \
                    b->d_start_dc, b->d_coef, b->d_status, b->d_wide
-    static const bool narrow = [] { const char *e = getenv("JDGPU_NARROW"); return !e || atoi(e) != 0; }();
+    const bool narrow = narrow_units();
     if (P.wwg_waves == JD_WWG_WAVES_BIG) {
         const dim3 grid(P.n_wwg), block(64 * JD_WWG_WAVES_BIG);
         if (narrow) { /* int8 buffers where the image allows, the wide kernel beside it for the rest */
@@ -2342,7 +2385,23 @@ extern "C" int jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *
     const jd_image &im = b->plan.img[i];
     size_t nb = im.n_blocks;
     std::vector<int16_t> tmp(nb * 64);
-    HIPCHK(hipMemcpy(tmp.data(), b->d_coef + (size_t)im.blk_off * 64, nb * 128, hipMemcpyDeviceToHost));
+    uint32_t is_wide = 1;
+    if (narrow_units()) HIPCHK(hipMemcpy(&is_wide, b->d_wide + i, 4, hipMemcpyDeviceToHost));
+    if (!is_wide) {
+        /* narrow image: 64-byte units of int8, the 12-bit DC value and the 4-bit last AC coefficient
+         * sharing bytes 0 and 63 (k_huff_write) */
+        std::vector<int8_t> t8(nb * JD_NARROW_UNIT);
+        HIPCHK(hipMemcpy(t8.data(), b->d_coef + (size_t)im.blk_off * 64, nb * JD_NARROW_UNIT, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < nb; ++k) {
+            const int8_t *u = &t8[k * 64];
+            for (int c = 0; c < 64; ++c) tmp[k * 64 + c] = u[c];
+            const int dc = ((uint8_t)u[0] | (((uint8_t)u[63] & 15) << 8));
+            tmp[k * 64] = (int16_t)((dc ^ 0x800) - 0x800);   /* sign-extend 12 bits */
+            tmp[k * 64 + 63] = (int16_t)(u[63] >> 4);
+        }
+    } else {
+        HIPCHK(hipMemcpy(tmp.data(), b->d_coef + (size_t)im.blk_off * 64, nb * 128, hipMemcpyDeviceToHost));
+    }
     for (size_t k = 0; k < nb; ++k)
         for (int z = 0; z < 64; ++z) dst[k * 64 + z] = tmp[k * 64 + jd_zigzag_to_cm[z]];
     return JDGPU_OK;
