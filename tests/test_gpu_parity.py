@@ -120,7 +120,7 @@ def _flat_block_jpeg(pkg, oracle, mcus, w, h):
     vals, lens, pred = [], [], [0, 0, 0]
     for triple in mcus:
         for c, v in enumerate(triple):
-            coef = (int(v) - 128) * 8            # flat unit: sample = DC / 8 + 128 (T[0][x]^2 / 4 = 1/8)
+            coef = int(round((v - 128) * 8))     # flat unit: sample = DC / 8 + 128 (T[0][x]^2 / 4 = 1/8)
             diff, pred[c] = coef - pred[c], coef
             cat = abs(diff).bit_length()
             code, ln = dc[c][cat]
@@ -653,6 +653,42 @@ print("retries", out.retries)
     # kernel must not add any while the flags are there, and must add one when they are not
     assert retries["narrow"] == retries["wide only"], retries
     assert retries["flags dropped"] > retries["wide only"], retries
+
+
+def test_narrow_units_and_what_does_not_fit_them(pkg, dec, oracle):
+    """A narrow image's coefficients travel from k_huff_write to k_pixel as 64-byte units: int8, the
+    DC value in 12 bits and the last AC coefficient in 4, sharing two bytes.  (1) Values at both ends
+    of those ranges come out right.  (2) An image whose AC values all fit int8 but whose last
+    coefficient needs more than 4 bits, and one whose DC value leaves 12 bits (no stream of 8-bit
+    samples does that; the reference just adds the differences up), are noticed by the flush, marked
+    wide and decoded again: same coefficients and pixels as the oracle, at least one more pass."""
+    yy, xx = np.mgrid[0:48, 0:64]
+
+    def checker(a):
+        g = (128 + a * (1 - 2 * ((xx + yy) & 1))).astype(np.uint8)
+        return pkg.synth.encode_rgb(np.stack([g, g, g], -1), quality=100, subsamp=0)
+    fits = checker(1)                                   # last coefficient within [-8, 7]
+    big63 = checker(10)
+    q_fit, q_big = oracle.qcoef(fits)[2], oracle.qcoef(big63)[2]
+    assert 0 < np.abs(q_fit[:, 63]).max() <= 7
+    assert np.abs(q_big[:, 63]).max() > 7 and np.abs(q_big[:, 1:]).max() <= 127
+    # flat units whose DC values climb out of 12 bits by differences that each fit the DC table
+    big_dc = _flat_block_jpeg(pkg, oracle, [(128 + 60 * k, 128 - 60 * k, 128) for k in range(12)], 8 * 4, 8 * 3)
+    q_dc = oracle.qcoef(big_dc)[2]
+    assert q_dc[:, 0].max() > 2047 and q_dc[:, 0].min() < -2048
+    # DC values at the ends of the 12 bits
+    seq = [2047, 0, -1, -2048, -1, 0] * 2              # every difference within the DC table's 11 bits
+    edge_dc = _flat_block_jpeg(pkg, oracle, [(128 + seq[k] / 8, 128 + seq[(k + 4) % 12] / 8, 128) for k in range(12)], 8 * 4, 8 * 3)
+    assert oracle.qcoef(edge_dc)[2][:, 0].max() == 2047 and oracle.qcoef(edge_dc)[2][:, 0].min() == -2048
+    ok = dec.decode([fits, edge_dc, golden_stream("syn_200x136_444_q95")])
+    for i, f in enumerate([fits, edge_dc]):
+        _check_against_oracle(pkg, oracle, ok, i, f)
+    assert ok.retries == 0
+    for f in (big63, big_dc):
+        out = dec.decode([fits, f, fits])
+        for i, g in enumerate([fits, f, fits]):
+            _check_against_oracle(pkg, oracle, out, i, g)
+        assert out.retries >= 1
 
 
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
