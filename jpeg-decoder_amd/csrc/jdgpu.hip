@@ -1005,11 +1005,21 @@ __constant__ uint8_t c_zz_cm[64];
  * flush queue).  A loop iteration decodes up to JD_WSTEPS symbols per lane -- a lane that has
  * completed a unit it owns pauses for the rest of the iteration, its buffer still holds that
  * unit -- and then the wave flushes the units completed in the iteration together: 8 lanes per
- * unit write its 128-byte line with one 16-byte store each (full, coalesced lines instead of
- * ~12 scattered 2-byte stores per unit) and clear the buffer.
+ * unit write it with one store each (whole 64-byte requests instead of ~12 scattered 2-byte stores
+ * per unit) and clear the buffer.  A wide unit leaves as 128 bytes of int16; a narrow one as
+ * JD_NARROW_UNIT = 64 bytes: int8 coefficients, the DC value in 12 bits (byte 0 and the low nibble
+ * of byte 63) and the last AC coefficient in the 4 bits left of byte 63.  The flush lanes check
+ * those two ranges; an image that breaks them is marked wide and the host runs the pass again,
+ * like one whose AC values the light decodes failed to flag.  Half the bytes matter because the
+ * kernel is limited by the per-CU path to L2 (TA / L1: TCP_PENDING_STALL_CYCLES 84 % of its
+ * time), whose traffic was two 64-byte write requests per unit plus the stream reads.
  * (Measured and rejected in round 2: DC differences into a side array, one 4-byte store per unit,
  * resolved by a scan kernel afterwards so that no decode has to read DC magnitudes: the 200 M
- * partial-line stores of a 4096 x 1080p batch cost 4.4 ms.)
+ * partial-line stores of a 4096 x 1080p batch cost 4.4 ms.  4 lanes per unit with two stores
+ * each: 9.9 against 8.6 ms.  Only whole passes of 8 units, the rest waiting an iteration: 9.0
+ * against 8.6 ms.  Stream loads in inline assembly with a hand-counted s_waitcnt, so that the
+ * refill does not wait for the flush stores' acknowledgements: no change.  16-byte and 8-byte
+ * stream loads into a register queue: more registers, 8.9 and 8.3 against 7.9 and 7.3 ms.)
  */
 #define WBUF_BYTES 128u
 #define JD_NARROW_UNIT 64u   /* bytes of a data unit in the coefficient buffer of a narrow image (a wide one: 128) */
@@ -1026,13 +1036,6 @@ __device__ __forceinline__ uint32_t wbuf_key(uint32_t lane) {
  * tell, `wide`).  The wide instantiation is launched beside it and takes the other images; each
  * skips the waves that are not its own. */
 __device__ __forceinline__ uint32_t nbuf_key(uint32_t lane) { return lane * 64u + ((lane & 7u) << 3); } /* address = idx ^ key */
-/* int8 pairs -> int16 pairs, two instructions per pair: v_perm_b32 puts each byte in the HIGH byte of
- * a 16-bit half (selector 0x0C = a zero byte), v_pk_ashrrev_i16 shifts both halves down with sign */
-__device__ __forceinline__ uint32_t widen_pair(uint32_t x, uint32_t sel) {
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 v = __builtin_bit_cast(s2, __builtin_amdgcn_perm(0u, x, sel)) >> (s2){8, 8};
-    return __builtin_bit_cast(uint32_t, v);
-}
 template <uint32_t WAVES, uint32_t SLOTS, bool NARROW, bool SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
