@@ -151,7 +151,9 @@ size_t   jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i);
  * (1920x1080: yes) is one dense [n][...] array starting at image 0 */
 void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);
 /* Quantised coefficients, [nblocks][64] int16 in ZIGZAG order, DC un-differenced, decode order
- * (the values src/decoding.c:44,65 computes before the multiply by the quantisation table). */
+ * (the values src/decoding.c:44,65 computes before the multiply by the quantisation table).
+ * Whatever form the device keeps them in (64-byte units of int8 for images without large AC
+ * values, 128-byte units of int16 otherwise) is expanded here. */
 int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
 /* HIP-event milliseconds per stage of the most recent decode (needs JDGPU_PROFILE). */
 int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
