@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_seg_scan(const jd_image *__restrict__ i
             v.n = c.x & (JD_CNT_WIDE - 1); v.d0 = c.y; v.d1 = c.z; v.d2 = c.w; v.f = first ? 1u : 0u;
             isw = (c.x & JD_CNT_WIDE) != 0;
         }
-        if (__any(isw) && lane == 0) atomicOr(&wide[blockIdx.x], 1u); /* see k_huff_first */
+        if ((__any(isw) || (base == 0 && wave == 0 && im.pre_wide)) && lane == 0) atomicOr(&wide[blockIdx.x], 1u); /* see k_huff_first */
         ScanVal own = v;
         /* wave-level inclusive scan (Hillis-Steele over 64 lanes) */
 #pragma unroll

@@ -114,6 +114,7 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut_hot *h, const jd_lut *t, uint32_t v16) {
 #define JD_ST_BAD 0x20000u
 #define JD_ST_NONE 0xFFFFFFFFu
 
+#define JD_NARROW_MIN_Q63 16u
 typedef struct {
     uint64_t raw_off;      /* byte offset of the stuffed scan in the raw buffer */
     uint64_t clean_off;    /* byte offset of the clean stream (multiple of JD_SEG_BYTES) */
@@ -141,7 +142,10 @@ typedef struct {
     uint8_t  blk_dc[JD_MAX_BPM];    /* lut slot of its DC / AC table */
     uint8_t  blk_ac[JD_MAX_BPM];
     uint8_t  comp_H[4], comp_V[4], comp_chan[4], comp_tq[4];
-    uint8_t  pad_[2];
+    uint8_t  pre_wide;              /* 1: take the wide (int16, 128-byte unit) path whatever the light decodes see:
+                                       a table whose last entry is below JD_NARROW_MIN_Q63 makes a last AC
+                                       coefficient beyond the narrow unit's 4 bits likely enough */
+    uint8_t  pad_[1];
     uint16_t quant[4][64];          /* dequantisation tables re-ordered for the pixel kernel:
                                        index = col*8 + row (column-major natural order) */
 } jd_image; /* keep a multiple of 8 bytes */

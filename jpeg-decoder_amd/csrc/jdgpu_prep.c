@@ -250,6 +250,13 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         }
         for (unsigned t = 0; t < 4; ++t)
             for (unsigned k = 0; k < 64; ++k) im->quant[t][jd_zigzag_to_cm[k]] = d->quant[t][k];
+        /* Narrow coefficient units keep the last zigzag coefficient in 4 bits; an image that breaks
+         * that costs its whole batch a second pass.  With a quantisation step of 16 or more there a
+         * value beyond +-7 needs a coefficient beyond +-120 at the highest frequency, which only
+         * synthetic checkerboards have; below, the image goes the wide way from the start. */
+        im->pre_wide = 0;
+        for (unsigned c = 0; c < nc; ++c)
+            if (d->quant[d->comp[c].Tq][63] < JD_NARROW_MIN_Q63) im->pre_wide = 1;
         im->mcus_x = (d->width + 8u * maxH - 1) / (8u * maxH);   /* src/jpeg.c:66-75 */
         im->mcus_y = (d->height + 8u * maxV - 1) / (8u * maxV);
         uint32_t nmcu = im->mcus_x * im->mcus_y;

@@ -97,14 +97,26 @@ def test_exhaustive_colour(pkg, dec, oracle):
     assert np.array_equal(pkg.ycbcr_to_rgb(img), oracle.to_rgb(img))
 
 
-def _flat_block_jpeg(pkg, oracle, mcus, w, h):
+def _flat_block_jpeg(pkg, oracle, mcus, w, h, q63=1):
     """a 4:4:4 stream with quantisation tables of ones whose 8x8 units are flat: `mcus` lists one
     (Y, Cb, Cr) sample triple per MCU (raster order).  Lets a test put ANY YCbCr triple in front
     of the colour stage, including ones no RGB image encodes to."""
     base = pkg.synth.make_jpeg(w, h, seed=1, quality=100, subsamp=0)
     d = pkg.parse(base)
     assert all(v == 1 for t in (0, 1) for v in d.quant[t])
-    hdr = base[:len(base) - d.scan_len]
+    hdr = bytearray(base[:len(base) - d.scan_len])
+    if q63 != 1:   # the last entry of every quantisation table (flat units have no AC value: the samples stay)
+        at = 0
+        while True:
+            at = hdr.find(b"\xff\xdb", at)
+            if at < 0:
+                break
+            n = (hdr[at + 2] << 8) | hdr[at + 3]
+            for t in range((n - 2) // 65):
+                assert hdr[at + 4 + 65 * t] < 16          # 8-bit entries
+                hdr[at + 4 + 65 * t + 64] = q63
+            at += 2 + n
+    hdr = bytes(hdr)
 
     def codes(spec):
         out, code, k = {}, 0, 0
@@ -666,19 +678,19 @@ def test_narrow_units_and_what_does_not_fit_them(pkg, dec, oracle):
 
     def checker(a):
         g = (128 + a * (1 - 2 * ((xx + yy) & 1))).astype(np.uint8)
-        return pkg.synth.encode_rgb(np.stack([g, g, g], -1), quality=100, subsamp=0)
-    fits = checker(1)                                   # last coefficient within [-8, 7]
-    big63 = checker(10)
+        return pkg.synth.encode_rgb(np.stack([g, g, g], -1), quality=85, subsamp=0)   # last table entry 30: not pre-marked wide
+    fits = checker(30)                                  # last coefficient within [-8, 7]
+    big63 = checker(60)
     q_fit, q_big = oracle.qcoef(fits)[2], oracle.qcoef(big63)[2]
     assert 0 < np.abs(q_fit[:, 63]).max() <= 7
     assert np.abs(q_big[:, 63]).max() > 7 and np.abs(q_big[:, 1:]).max() <= 127
     # flat units whose DC values climb out of 12 bits by differences that each fit the DC table
-    big_dc = _flat_block_jpeg(pkg, oracle, [(128 + 60 * k, 128 - 60 * k, 128) for k in range(12)], 8 * 4, 8 * 3)
+    big_dc = _flat_block_jpeg(pkg, oracle, [(128 + 60 * k, 128 - 60 * k, 128) for k in range(12)], 8 * 4, 8 * 3, q63=16)
     q_dc = oracle.qcoef(big_dc)[2]
     assert q_dc[:, 0].max() > 2047 and q_dc[:, 0].min() < -2048
     # DC values at the ends of the 12 bits
     seq = [2047, 0, -1, -2048, -1, 0] * 2              # every difference within the DC table's 11 bits
-    edge_dc = _flat_block_jpeg(pkg, oracle, [(128 + seq[k] / 8, 128 + seq[(k + 4) % 12] / 8, 128) for k in range(12)], 8 * 4, 8 * 3)
+    edge_dc = _flat_block_jpeg(pkg, oracle, [(128 + seq[k] / 8, 128 + seq[(k + 4) % 12] / 8, 128) for k in range(12)], 8 * 4, 8 * 3, q63=16)
     assert oracle.qcoef(edge_dc)[2][:, 0].max() == 2047 and oracle.qcoef(edge_dc)[2][:, 0].min() == -2048
     ok = dec.decode([fits, edge_dc, golden_stream("syn_200x136_444_q95")])
     for i, f in enumerate([fits, edge_dc]):
@@ -689,6 +701,13 @@ def test_narrow_units_and_what_does_not_fit_them(pkg, dec, oracle):
         for i, g in enumerate([fits, f, fits]):
             _check_against_oracle(pkg, oracle, out, i, g)
         assert out.retries >= 1
+    # a table whose last entry is below 16 sends the image the wide way from the start: no second pass
+    fine = pkg.synth.encode_rgb(np.stack([(128 + 10 * (1 - 2 * ((xx + yy) & 1))).astype(np.uint8)] * 3, -1), quality=100, subsamp=0)
+    q_fine = oracle.qcoef(fine)[2]
+    assert np.abs(q_fine[:, 63]).max() > 7 and np.abs(q_fine[:, 1:]).max() <= 127
+    out = dec.decode([fits, fine])
+    _check_against_oracle(pkg, oracle, out, 1, fine)
+    assert out.retries == 0
 
 
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
