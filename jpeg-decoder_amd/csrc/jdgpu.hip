@@ -494,12 +494,12 @@ __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
  *           the high 32 - r bits of w1 -- one v_alignbit_b32.  Consuming bits decrements r; when
  *           w0 is used up the window shifts by a word (two selects), which two symbols of at
  *           most 31 bits can do twice: w2 is what the second shift moves in.
- *   refill  once per iteration, for all lanes, outside any divergent code: the words the shifts
- *           used up come from (qa, qb), which were loaded at the END OF THE PREVIOUS iteration,
- *           and (qa, qb) are loaded again.  So no load is ever waited for right after its issue
- *           (the compiler places the wait at the first use), the L2 / Infinity Cache latency has
- *           a whole iteration to pass, and there is no refill branch that some lane of the wave
- *           takes in every step anyway.
+ *   refill  after every second symbol step, for all lanes, outside any divergent code: the words
+ *           the shifts used up come from (qa, qb) = words c and c + 1, loaded at an EARLIER
+ *           refill, and the lanes whose window moved load the words the queue now lacks.  So no
+ *           load is ever waited for right after its issue (the compiler places the wait at the
+ *           first use), the L2 / Infinity Cache latency has two steps to pass, and there is no
+ *           refill branch that some lane of the wave takes in every step anyway.
  */
 #ifndef JD_RSTEPS
 #define JD_RSTEPS 2
@@ -1505,10 +1505,13 @@ __device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t 
 /*
  * k_pixel: one work-group per strip of an MCU row (JD_STRIP_PX pixels wide); each of its
  * waves owns a 64-pixel-wide part and runs both phases on it without any work-group barrier:
- *   phase 1: 8 lanes per data unit.  Lane u loads column u of the unit (coefficients are stored
- *            column-major: 16 contiguous bytes), dequantises, does the vertical 8-point
- *            transform, transposes through LDS (within the wave), does the horizontal transform
- *            for row y, rounds and writes 8 samples of one row into the component's sample tile.
+ *   phase 1: 8 lanes per data unit, 8 units at a time, luma units first, then Cb, then Cr.
+ *            Lane u loads column u of the unit (coefficients are stored column-major: 16
+ *            contiguous bytes of int16, or 8 of int8 in a narrow image), dequantises, does the
+ *            vertical 8-point transform, transposes through LDS (within the wave), does the
+ *            horizontal transform for row y, rounds and writes 8 samples of one row into the
+ *            component's sample tile.  A group of units without a coefficient of frequency 4 or
+ *            more in either direction takes both passes with half the terms.
  *   phase 2: 4 pixels per lane (x 2 rows when chroma is shared vertically): gather Y/Cb/Cr
  *            (replicated chroma), colour transform, one 12-byte store; 16 lanes cover 192
  *            contiguous bytes of an output row.
