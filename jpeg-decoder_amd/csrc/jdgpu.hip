@@ -848,8 +848,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__re
                                                             const uint32_t *__restrict__ st_in,
                                                             const uint32_t *__restrict__ st_exit,
                                                             uint32_t *__restrict__ list,
-                                                            uint32_t *__restrict__ list_cnt) {
+                                                            uint32_t *__restrict__ list_cnt,
+                                                            const uint32_t *__restrict__ prev_cnt /* null in the first round of a pass */) {
     const jd_huff_wg wg = wave_desc(wgs, JD_WG_WAVES);
+    /* a segment's start can only break when its predecessor was decoded again, i.e. was on the
+     * previous round's list: an image whose list was empty then has nothing to check now */
+    if (prev_cnt != nullptr && prev_cnt[wg.img] == 0u) return;
     const jd_image &im = imgs[wg.img];
     const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
     bool broken = false;
@@ -2258,7 +2262,7 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     for (uint32_t r = 0; r < JD_REPAIR_ROUNDS; ++r) {
         uint32_t *lc = b->d_list_cnt + (size_t)r * P.n;
         hipLaunchKernelGGL(k_chain_check, grid, block, 0, st, b->d_img, b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit,
-                           b->d_list, lc);
+                           b->d_list, lc, r ? lc - P.n : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_huff_repair, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_rpl,
                            b->d_list, lc, b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     }
