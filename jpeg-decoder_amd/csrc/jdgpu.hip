@@ -1264,8 +1264,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
 
 /* 8-point inverse transform with the reference's table, even/odd split:
  * out[x] = S * sum_u in[u] * T[u][x];  T[u][7-x] = (-1)^u T[u][x].  S is a power of two, so
- * scaling the constants is exact and commutes with every rounding (S = 1/4 folds the
- * reference's final "sum / 4", src/decoding.c:83, into the second pass). */
+ * scaling the constants is exact and commutes with every rounding.  Both passes run with S = 1:
+ * the reference's final "sum / 4" (src/decoding.c:83) is taken by the rounding add (to_int128) --
+ * one set of constants in scalar registers, which ended the kernel's scalar register spills
+ * (10.4 -> 10.0 ms). */
 /* pix_real: the arithmetic type of the IDCT.  double is the product (byte-identical to the reference on
  * every fixture); JD_ABL_PIX_F32 builds the all-float variant for the round-2 measurement of what
  * f32 would buy, never shipped. */
@@ -1316,9 +1318,13 @@ __device__ __forceinline__ void idct8_low(const pix_real in[4], pix_real out[8])
  * half-integer.  One f64 add, no conversion instruction; the clamp is done on pairs (below). */
 __device__ __forceinline__ int to_int128(pix_real v) {
 #ifdef JD_ABL_PIX_F32
-    return __float2int_rn(v) + 128;
+    return __float2int_rn(v * 0.25f) + 128;
 #else
-    return __double2loint(v + (6755399441055744.0 + 128.0));
+    /* v is FOUR times the sample (the reference's "sum / 4", src/decoding.c:83, is left to this
+     * add: with 1.5 * 2^54 the unit in the last place is 4, so the mantissa's low word is
+     * RN(v / 4) + 128 -- the same bits as scaling the second pass's constants by 1/4, a power of
+     * two, and one set of seven constants in scalar registers instead of two) */
+    return __double2loint(v + (27021597764222976.0 + 512.0));
 #endif
 }
 __device__ __forceinline__ uint32_t cvt_pk_i16(int lo, int hi) {          /* v_cvt_pk_i16_i32: both saturated to 16 bits */
@@ -1724,7 +1730,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     if (act) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
-                        idct8_low<1>(col, t);
+                        idct8_low<0>(col, t);
                         put_row(t, toff);
                     }
                 } else {
@@ -1738,7 +1744,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     if (act) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) col[u] = tr[(l ^ sx) * 8u + ((u + l) & 7u)];
-                        idct8<1>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
+                        idct8<0>(col, t); /* horizontal: row y = l, t[x] = sample - 128 before rounding */
                         put_row(t, toff);
                     }
                 }
