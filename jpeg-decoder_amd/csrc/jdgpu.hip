@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         const uint32_t p23 = sat_pk_u8(cvt_pk_i16(to_int128(t[2]), to_int128(t[3])));
         const uint32_t p45 = sat_pk_u8(cvt_pk_i16(to_int128(t[4]), to_int128(t[5])));
         const uint32_t p67 = sat_pk_u8(cvt_pk_i16(to_int128(t[6]), to_int128(t[7])));
-        *reinterpret_cast<uint2 *>(&tile[toff]) = make_uint2(p01 | (p23 << 16), p45 | (p67 << 16));
+        *reinterpret_cast<uint2 *>(&tile[toff]) = make_uint2(pack16((int)p01, (int)p23), pack16((int)p45, (int)p67));
     };
     /* the first 24 units of a row (all of them in most layouts) sit in the same places in every MCU row */
     uint32_t g_toff[3] = {0, 0, 0}, g_qoff[3] = {0, 0, 0}, g_uoff[3] = {0, 0, 0};
@@ -1770,7 +1770,9 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                 constexpr uint32_t STEP = VSH ? 2u : 4u;      /* without vertical sharing: rows rq, rq + 4 (1 apart in a group) */
                 constexpr uint32_t CB = 4u >> HSH;            /* chroma bytes under the lane's 4 pixels */
                 uint32_t offC = rp0 * PIX_ROW + CB * g;
-                for (uint32_t rp = rp0; rp < rp0 + 2u * STEP && (rp << VSH) < rows; rp += STEP, offC += STEP * PIX_ROW) {
+                uint32_t at = __umul24(rp0 << VSH, W) + x;          /* pixel index in the MCU row's output; carried, like offC */
+                const uint32_t at_step = __umul24(STEP << VSH, W);
+                for (uint32_t rp = rp0; rp < rp0 + 2u * STEP && (rp << VSH) < rows; rp += STEP, offC += STEP * PIX_ROW, at += at_step) {
                     uint32_t cbv[4], crv[4];
                     if (GRAY) {
 #pragma unroll
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         if (r < rows) {
                             uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[offY + dy * PIX_ROW]);
                             Px4 v = OUT_YCBCR ? ycc4(y4, cbv, crv) : rgb4(y4, ct);
-                            store_px4<FMT>(orow, plane, __umul24(r, W) + x, v, aligned, npx);
+                            store_px4<FMT>(orow, plane, at + (dy ? W : 0u), v, aligned, npx);
                         }
                     }
                 }
