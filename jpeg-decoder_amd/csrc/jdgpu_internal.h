@@ -114,7 +114,7 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut_hot *h, const jd_lut *t, uint32_t v16) {
 #define JD_ST_BAD 0x20000u
 #define JD_ST_NONE 0xFFFFFFFFu
 
-#define JD_NARROW_MIN_Q63 16u
+#define JD_NARROW_MIN_Q63 8u
 typedef struct {
     uint64_t raw_off;      /* byte offset of the stuffed scan in the raw buffer */
     uint64_t clean_off;    /* byte offset of the clean stream (multiple of JD_SEG_BYTES) */

@@ -701,7 +701,7 @@ def test_narrow_units_and_what_does_not_fit_them(pkg, dec, oracle):
         for i, g in enumerate([fits, f, fits]):
             _check_against_oracle(pkg, oracle, out, i, g)
         assert out.retries >= 1
-    # a table whose last entry is below 16 sends the image the wide way from the start: no second pass
+    # a table whose last entry is below 8 sends the image the wide way from the start: no second pass
     fine = pkg.synth.encode_rgb(np.stack([(128 + 10 * (1 - 2 * ((xx + yy) & 1))).astype(np.uint8)] * 3, -1), quality=100, subsamp=0)
     q_fine = oracle.qcoef(fine)[2]
     assert np.abs(q_fine[:, 63]).max() > 7 and np.abs(q_fine[:, 1:]).max() <= 127
