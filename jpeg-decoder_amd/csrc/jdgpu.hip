@@ -445,21 +445,24 @@ struct SegTables {
 template <bool LIGHT>
 __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top) {
     const uint32_t off = isdc ? desc.dc_off : desc.ac_off;
-    /* read sign-extended: link entries (bit 15) are the negative ones, no mask needed to tell */
-    /* v_bfe_u32 + v_lshl_add_u32 (the builtin keeps the compiler from folding the two shifts into
-     * shift + mask + add) */
-    const int se = *reinterpret_cast<const int16_t *>(T.lut + (__builtin_amdgcn_ubfe(top, 32 - JD_LUT_BITS, JD_LUT_BITS) * 2u + off));
-    uint32_t e = (uint32_t)se;
-    if (__builtin_expect(se < 0, 0)) {
+    /* v_bfe_u32 + v_lshl_add_u32 (through asm: the compiler folds the two shifts of the C form into
+     * shift + mask + add); the entry is read zero-extended, link entries are the ones whose 16-bit
+     * value has bit 15 set (an unsigned compare: a 16-bit signed one makes the compiler re-mask the entry) */
+    uint32_t idx;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(idx) : "v"(top), "n"(32 - JD_LUT_BITS), "n"(JD_LUT_BITS));
+    uint32_t e = *reinterpret_cast<const uint16_t *>(T.lut + (idx * 2u + off));
+    asm("" : "+v"(e));   /* hides the 16-bit origin, or the compare below becomes a 16-bit one plus a mask */
+    if (__builtin_expect(e > 0x7FFFu, 0)) {
         const uint32_t first = e & 0xFFFu;
         if (__builtin_expect(first == JD_LUT_NOSUB, 0)) {
-            const uint32_t slot = isdc ? (desc.slots & 15u) : (desc.slots >> 4);
+            uint32_t slot = isdc ? (desc.slots & 15u) : (desc.slots >> 4);
+            asm volatile("" : "+v"(slot));   /* keeps the address arithmetic of this (very rare) path inside it */
             const jd_sym s = jd_lut_lookup_canon(T.glut + slot, top >> 16);
             e = LIGHT ? light_entry(s.len, s.size, s.run, s.bad != 0, isdc) : write_entry(s.len, s.size, s.run, s.bad != 0, isdc);
         } else {
             const uint32_t rest = (top >> 16) & ((1u << (16 - JD_LUT_BITS)) - 1u);
-            const uint32_t idx = first + (rest >> ((16 - JD_LUT_BITS) - ((e >> 12) & 7u)));
-            e = *reinterpret_cast<const uint16_t *>(T.lut + off + sizeof(uint16_t) * ((1u << JD_LUT_BITS) + idx));
+            const uint32_t idx2 = first + (rest >> ((16 - JD_LUT_BITS) - ((e >> 12) & 7u)));
+            e = *reinterpret_cast<const uint16_t *>(T.lut + off + sizeof(uint16_t) * ((1u << JD_LUT_BITS) + idx2));
         }
     }
     return e;
