@@ -147,7 +147,8 @@ def run_workload(pkg, torch, dist, name, batch_n, distinct, steps, warmup, layou
     files = make_files(pkg, name, distinct)
     descs = pkg.parse_many(files)
     idx = batch_indices(pkg, name, descs, batch_n, world, rank)
-    layout_flag = {"rgb": 0, "rgba": pkg.OUT_4BYTE, "planar": pkg.OUT_PLANAR}[layout]
+    layout_flag = {"rgb": 0, "rgba": pkg.OUT_4BYTE, "planar": pkg.OUT_PLANAR, "rgb-pitched": pkg.OUT_PITCHED,
+                   "rgba-pitched": pkg.OUT_4BYTE | pkg.OUT_PITCHED, "planar-pitched": pkg.OUT_PLANAR | pkg.OUT_PITCHED}[layout]
     batch = pkg.Batch([descs[i] for i in idx], flags=pkg.OUT_RGB | pkg.PROFILE | layout_flag)
 
     def barrier():
@@ -309,7 +310,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lean", action="store_true", help="headline workload only: no pcie_inclusive, no other_workloads")
-    ap.add_argument("--layout", default="rgb", choices=["rgb", "rgba", "planar"],
+    ap.add_argument("--layout", default="rgb", choices=["rgb", "rgba", "planar", "rgb-pitched", "rgba-pitched", "planar-pitched"],
                     help="output layout (default: the reference's 3-byte pixel[]; the others are SURVEY 8 row f3)")
     args = ap.parse_args()
 
@@ -336,7 +337,7 @@ def main():
     desc, batch_n, distinct = WORKLOADS[args.workload]
     batch_n = args.batch or batch_n
     distinct = min(args.distinct or distinct, batch_n)
-    px_bytes = 4 if args.layout == "rgba" else 3
+    px_bytes = 4 if args.layout.startswith("rgba") else 3
 
     res = run_workload(pkg, torch, dist, args.workload, batch_n, distinct, args.steps, args.warmup, args.layout,
                        world, rank, rehearsal)

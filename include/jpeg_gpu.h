@@ -74,7 +74,13 @@ enum {
      * interleaved layout is what the reference's callers get; loaders want one of these).  Same
      * sample values, rows without padding; combine with JDGPU_OUT_RGB or JDGPU_OUT_YCBCR. */
     JDGPU_OUT_4BYTE = 8,      /* 4 interleaved bytes per pixel, the fourth = 255 (RGBA / YCbCrA) */
-    JDGPU_OUT_PLANAR = 16     /* three planes of width*height bytes, in channel order ([3][H][W]) */
+    JDGPU_OUT_PLANAR = 16,    /* three planes of width*height bytes, in channel order ([3][H][W]) */
+    /* padded pitch (row f3): every output row starts on a 256-byte boundary.  The row stride is the
+     * width rounded up to 256 pixels (3-byte pixels, planes) or 64 pixels (4-byte pixels);
+     * jdgpu_batch_pixel_pitch tells it in bytes.  Padding bytes are zero and are never written by a
+     * decode.  Combines with every layout above; rows of any width are then stored with whole
+     * dwords (the unpadded 3-byte layout goes byte by byte when width % 4 != 0). */
+    JDGPU_OUT_PITCHED = 32
 };
 
 /* stages reported by jdgpu_batch_stage_ms */
@@ -142,10 +148,15 @@ uint64_t jdgpu_batch_total_pixels(const jdgpu_batch *b);            /* sum of wi
 uint64_t jdgpu_batch_total_blocks(const jdgpu_batch *b);            /* 8x8 data units */
 uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b);
 size_t   jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i);
-/* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14); with JDGPU_OUT_4BYTE or
- * JDGPU_OUT_PLANAR the layout chosen at creation (jdgpu_batch_pixel_bytes tells the size) */
+/* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14); with JDGPU_OUT_4BYTE,
+ * JDGPU_OUT_PLANAR or JDGPU_OUT_PITCHED the layout chosen at creation, padding included
+ * (jdgpu_batch_pixel_bytes tells the size) */
 int      jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst);
 size_t   jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i);
+/* bytes from one row to the next (of a plane, with JDGPU_OUT_PLANAR: the planes are then
+ * pitch * height bytes apart): width * bytes per pixel, or the padded pitch with JDGPU_OUT_PITCHED.
+ * pixel_bytes = pitch * height (* 3 for planes).  src/image.h:4-14 has no pitch: rows are dense. */
+size_t   jdgpu_batch_pixel_pitch(const jdgpu_batch *b, size_t i);
 /* device pointer, same layout; image i starts on a 256-byte boundary, and images of a batch lie
  * one after the other -- a batch of equal-sized images whose size is a multiple of 256 bytes
  * (1920x1080: yes) is one dense [n][...] array starting at image 0 */

@@ -20,7 +20,7 @@ OK = 0
 ERR_HEADER = -1
 ERR_NO_DEVICE = -10
 IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
-OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR = 0, 1, 2, 8, 16
+OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR, OUT_PITCHED = 0, 1, 2, 8, 16, 32
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 
 EXPORTS = [
@@ -28,7 +28,7 @@ EXPORTS = [
     "jdgpu_batch_create", "jdgpu_batch_decode", "jdgpu_batch_sync", "jdgpu_batch_destroy",
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
-    "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
+    "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_pixel_pitch", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_rgb_to_ycbcr",
     "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
@@ -103,6 +103,8 @@ def lib():
     L.jdgpu_batch_read_pixels.argtypes = [vp, sz, vp]
     L.jdgpu_batch_pixel_bytes.argtypes = [vp, sz]
     L.jdgpu_batch_pixel_bytes.restype = sz
+    L.jdgpu_batch_pixel_pitch.argtypes = [vp, sz]
+    L.jdgpu_batch_pixel_pitch.restype = sz
     L.jdgpu_batch_device_pixels.argtypes = [vp, sz]
     L.jdgpu_batch_device_pixels.restype = vp
     L.jdgpu_batch_read_coefficients.argtypes = [vp, sz, vp]
@@ -234,13 +236,31 @@ class Batch:
             return (3, h, w)
         return (h, w, 4 if self.flags & OUT_4BYTE else 3)
 
-    def pixels(self, i):
-        out = np.empty(self.shape(i), np.uint8)
-        assert out.nbytes == self._L.jdgpu_batch_pixel_bytes(self._h, i)
+    def pitch(self, i):
+        """bytes from one output row to the next (of a plane, in the planar layout)"""
+        return int(self._L.jdgpu_batch_pixel_pitch(self._h, i))
+
+    def strides(self, i):
+        """byte strides that go with shape(i): dense unless the batch was created with OUT_PITCHED"""
+        w, h = self.dims[i]
+        p = self.pitch(i)
+        if self.flags & OUT_PLANAR:
+            return (p * h, p, 1)
+        return (p, 4 if self.flags & OUT_4BYTE else 3, 1)
+
+    def padded(self, i):
+        """the output buffer of image i as the device holds it, row padding included (flat bytes)"""
+        out = np.empty(self._L.jdgpu_batch_pixel_bytes(self._h, i), np.uint8)
         rc = self._L.jdgpu_batch_read_pixels(self._h, i, out.ctypes.data)
         if rc:
             raise _err(self._L, "jdgpu_batch_read_pixels", rc)
         return out
+
+    def pixels(self, i):
+        buf = self.padded(i)
+        if not self.flags & OUT_PITCHED:
+            return buf.reshape(self.shape(i))
+        return np.lib.stride_tricks.as_strided(buf, self.shape(i), self.strides(i)).copy()
 
     rgb = pixels
 
@@ -301,13 +321,20 @@ class Batch:
     def tensor(self, i):
         """image i as a torch uint8 tensor on the GPU that ALIASES the batch's output buffer (no
         copy; valid until the batch is closed or decoded again; synchronise first)."""
-        return _device_view(self, self.device_pixels(i), self.shape(i))
+        return _device_view(self, self.device_pixels(i), self.shape(i),
+                            self.strides(i) if self.flags & OUT_PITCHED else None)
+
+    def dlpack(self, i):
+        """image i as a DLPack capsule over the batch's output buffer (row f3 of SURVEY 8: any
+        DLPack consumer takes it without a copy; pitched rows come through as strides)"""
+        import torch.utils.dlpack
+        return torch.utils.dlpack.to_dlpack(self.tensor(i))
 
     def tensor_all(self):
         """the whole batch as one [n, ...] tensor aliasing the output buffer; only for batches of
         equal-sized images whose byte size is a multiple of 256 (images start on 256 bytes)"""
-        if self.n == 0 or len(set(self.dims)) != 1:
-            raise JpegError("tensor_all needs a non-empty batch of equal-sized images")
+        if self.n == 0 or len(set(self.dims)) != 1 or self.flags & OUT_PITCHED:
+            raise JpegError("tensor_all needs a non-empty batch of equal-sized images with dense rows")
         nbytes = int(np.prod(self.shape(0)))
         if self.n > 1 and self.device_pixels(1) - self.device_pixels(0) != nbytes:
             raise JpegError(f"images of {nbytes} bytes are padded to 256-byte starts: not one dense array")
@@ -328,18 +355,19 @@ class Batch:
 class _DeviceArray:
     """__cuda_array_interface__ over a region of a batch's output buffer (keeps the batch alive)"""
 
-    def __init__(self, owner, ptr, shape):
+    def __init__(self, owner, ptr, shape, strides=None):
         self._owner = owner
         self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "|u1",
-                                         "data": (int(ptr), False), "version": 2, "strides": None}
+                                         "data": (int(ptr), False), "version": 2,
+                                         "strides": None if strides is None else tuple(int(x) for x in strides)}
 
 
-def _device_view(owner, ptr, shape):
+def _device_view(owner, ptr, shape, strides=None):
     import torch
     if not ptr:
         raise JpegError("the batch has no device output buffer")
     dev = torch.device("cuda", torch.cuda.current_device())
-    return torch.as_tensor(_DeviceArray(owner, ptr, shape), device=dev)
+    return torch.as_tensor(_DeviceArray(owner, ptr, shape, strides), device=dev)
 
 
 class Decoder:

@@ -1464,7 +1464,7 @@ template <uint32_t FMT>
 __device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t at, const Px4 &v, bool aligned,
                                           uint32_t npx) {
     /* rows: the image's output at the first pixel row of this MCU row (wave-uniform: a scalar base);
-     * at = r * width + x within it (< 2^22: r < 32, width < 2^16), so every address is the scalar
+     * at = r * stride + x within it (< 2^22: r < 32, stride <= 2^16), so every address is the scalar
      * base plus a 32-bit lane offset; plane = width * height.  v_perm_b32 picks the output bytes:
      * selector 0..3 = bytes of the second operand, 4..7 = of the first, 0x0D = 0xFF */
     if (FMT == JD_FMT_PLANAR) {
@@ -1472,7 +1472,7 @@ __device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t 
         for (int c = 0; c < 3; ++c) {
             const uint32_t w = __builtin_amdgcn_perm(v.c13[c], v.c02[c], 0x05010400u);   /* pixels 0, 1, 2, 3 */
             uint8_t *dst = rows + c * plane + at;
-            if (aligned) *reinterpret_cast<uint32_t *>(dst) = w;       /* W % 4 == 0 */
+            if (aligned) *reinterpret_cast<uint32_t *>(dst) = w;       /* stride % 4 == 0, four pixels */
             else
                 for (uint32_t i = 0; i < npx; ++i) dst[i] = (uint8_t)(w >> (8 * i));
         }
@@ -1615,14 +1615,17 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const char *cbase = reinterpret_cast<const char *>(coef + (size_t)im.blk_off * 64) +
                         ((size_t)wg.mcu_row * im.mcus_x + mcu_first) * bpm * ub;
     const uint32_t W = im.width, H = im.height;
+    const uint32_t S = im.stride;   /* pixels from one output row to the next (W unless the rows are pitched) */
     const uint32_t x0 = mcu_first * 8u * maxH;
     const uint32_t g = lane & 15u, rq = lane >> 4, x = x0 + 4u * g;
     uint8_t *out = pix + im.pix_off;
-    const bool aligned = ((W & 3u) == 0);
     const bool draws = x < W && 4u * g < my_mcus * 8u * maxH;   /* lane has pixels in phase 2 */
     const uint32_t npx = draws ? min(4u, W - x) : 0u;
+    /* whole-dword stores: rows that start on a dword and a lane with all four pixels (pitched rows of a
+     * ragged width: only the last lane of a row goes byte by byte, the padding stays zero) */
+    const bool aligned = ((S & 3u) == 0) && npx == 4u;
     const uint8_t *tY = tile, *tB = tile + PLANE1, *tR = tile + PLANE2;
-    const size_t plane = (size_t)W * H;
+    const size_t plane = (size_t)S * H;
 
     /* A wave walks down pix_rows MCU rows.  All coefficient loads of the first 24 units of a
      * row (all of them for 4:2:0 and 4:4:4) are issued one row AHEAD: a wave that loaded, waited
@@ -1759,7 +1762,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
         const uint32_t y0 = mrow * 8u * maxV;
         const uint32_t rows = min(8u * maxV, H - y0);
         /* output of pixel row y0 (wave-uniform): plane 0 of the planar layout, else the interleaved pixels */
-        uint8_t *const orow = out + (size_t)y0 * W * (FMT == JD_FMT_PLANAR ? 1u : FMT == JD_FMT_4 ? 4u : 3u);
+        uint8_t *const orow = out + (size_t)y0 * S * (FMT == JD_FMT_PLANAR ? 1u : FMT == JD_FMT_4 ? 4u : 3u);
         if (draws) {
             /* 24-bit multiplies for the row offsets and the pixel index (rows, widths < 2^16): a
              * full 32-bit or 64-bit multiply costs as much as four plain instructions */
@@ -1773,8 +1776,8 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                 constexpr uint32_t STEP = VSH ? 2u : 4u;      /* without vertical sharing: rows rq, rq + 4 (1 apart in a group) */
                 constexpr uint32_t CB = 4u >> HSH;            /* chroma bytes under the lane's 4 pixels */
                 uint32_t offC = rp0 * PIX_ROW + CB * g;
-                uint32_t at = __umul24(rp0 << VSH, W) + x;          /* pixel index in the MCU row's output; carried, like offC */
-                const uint32_t at_step = __umul24(STEP << VSH, W);
+                uint32_t at = __umul24(rp0 << VSH, S) + x;          /* pixel index in the MCU row's output; carried, like offC */
+                const uint32_t at_step = __umul24(STEP << VSH, S);
                 for (uint32_t rp = rp0; rp < rp0 + 2u * STEP && (rp << VSH) < rows; rp += STEP, offC += STEP * PIX_ROW, at += at_step) {
                     uint32_t cbv[4], crv[4];
                     if (GRAY) {
@@ -1808,7 +1811,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         if (r < rows) {
                             uint32_t y4 = *reinterpret_cast<const uint32_t *>(&tY[offY + dy * PIX_ROW]);
                             Px4 v = OUT_YCBCR ? ycc4(y4, cbv, crv) : rgb4(y4, ct);
-                            store_px4<FMT>(orow, plane, at + (dy ? W : 0u), v, aligned, npx);
+                            store_px4<FMT>(orow, plane, at + (dy ? S : 0u), v, aligned, npx);
                         }
                     }
                 }
@@ -1841,7 +1844,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                         for (int i = 0; i < 4; ++i) ct[i] = chroma_lookup(s_ctab, sm[1][i], sm[2][i]);
                         v = rgb4(y4, ct);
                     }
-                    store_px4<FMT>(orow, plane, __umul24(r, W) + x, v, aligned, npx);
+                    store_px4<FMT>(orow, plane, __umul24(r, S) + x, v, aligned, npx);
                 }
             }
         }
@@ -2130,7 +2133,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t0 = now();
-    TRY(jd_plan_build(descs, n, (flags & JDGPU_OUT_4BYTE) ? 4u : 3u, &b->plan, g_err, sizeof g_err));
+    TRY(jd_plan_build(descs, n, (flags & JDGPU_OUT_4BYTE) ? 4u : 3u, (flags & JDGPU_OUT_PITCHED) ? 1u : 0u, &b->plan, g_err, sizeof g_err));
     jd_plan &P = b->plan;
     if (trace) { fprintf(stderr, "[jdgpu] plan %.1f ms\n", now() - t0); t0 = now(); }
     b->status.assign(n, 0);
@@ -2392,13 +2395,18 @@ extern "C" void *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i) {
 extern "C" int jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst) {
     if (!b || i >= b->plan.n || !dst) return JDGPU_ERR_ARG;
     const jd_image &im = b->plan.img[i];
-    HIPCHK(hipMemcpy(dst, b->d_pix + im.pix_off, (size_t)im.width * im.height * b->plan.px_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, b->d_pix + im.pix_off, (size_t)im.stride * im.height * b->plan.px_bytes, hipMemcpyDeviceToHost));
     return JDGPU_OK;
 }
 
 extern "C" size_t jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i) {
     if (!b || i >= b->plan.n) return 0;
-    return (size_t)b->plan.img[i].width * b->plan.img[i].height * b->plan.px_bytes;
+    return (size_t)b->plan.img[i].stride * b->plan.img[i].height * b->plan.px_bytes;
+}
+
+extern "C" size_t jdgpu_batch_pixel_pitch(const jdgpu_batch *b, size_t i) {
+    if (!b || i >= b->plan.n) return 0;
+    return (size_t)b->plan.img[i].stride * ((b->flags & JDGPU_OUT_PLANAR) ? 1u : b->plan.px_bytes);
 }
 
 extern "C" int jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst) {

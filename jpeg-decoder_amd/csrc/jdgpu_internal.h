@@ -146,6 +146,9 @@ typedef struct {
                                        a table whose last entry is below JD_NARROW_MIN_Q63 makes a last AC
                                        coefficient beyond the narrow unit's 4 bits likely enough */
     uint8_t  pad_[1];
+    uint32_t stride;                /* output pixels from one row to the next: width, or with JDGPU_OUT_PITCHED the
+                                       next count that puts every row on a 256-byte boundary */
+    uint32_t pad2_;
     uint16_t quant[4][64];          /* dequantisation tables re-ordered for the pixel kernel:
                                        index = col*8 + row (column-major natural order) */
 } jd_image; /* keep a multiple of 8 bytes */
@@ -200,9 +203,10 @@ typedef struct {
     uint32_t n_u;            /* entries of the interval-offset array */
     uint64_t total_pixels, total_blocks, pix_bytes;
     uint32_t px_bytes;     /* output bytes per pixel: 3, or 4 with JDGPU_OUT_4BYTE */
+    uint32_t pitched;      /* rows start on 256-byte boundaries (JDGPU_OUT_PITCHED) */
 } jd_plan;
 
-int  jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd_plan *plan, char *err, size_t errlen);
+int  jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, unsigned pitched, jd_plan *plan, char *err, size_t errlen);
 void jd_plan_gather(jd_plan *plan, const jdgpu_image_desc *descs, size_t n); /* copies the scans into plan->raw (threads) */
 void jd_plan_free(jd_plan *plan);
 int  jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut);

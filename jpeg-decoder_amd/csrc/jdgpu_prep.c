@@ -156,10 +156,11 @@ void jd_plan_gather(jd_plan *P, const jdgpu_image_desc *descs, size_t n) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd_plan *P, char *err, size_t errlen) {
+int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, unsigned pitched, jd_plan *P, char *err, size_t errlen) {
     memset(P, 0, sizeof *P);
     P->n = n;
     P->px_bytes = px_bytes;
+    P->pitched = pitched;
     P->img = calloc(n ? n : 1, sizeof *P->img);
     P->luts = calloc((n ? n : 1) * JD_LUT_SLOTS, sizeof *P->luts);
     if (!P->img || !P->luts) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
@@ -197,7 +198,10 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, jd
         im->width = d->width; im->height = d->height;
         im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
         im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
-        pix += align_up((size_t)d->width * d->height * px_bytes, 256);
+        /* row stride in pixels.  Pitched: 3-byte pixels and the 1-byte rows of a plane need a multiple of
+         * 256 pixels for rows on 256-byte boundaries, 4-byte pixels a multiple of 64 */
+        im->stride = pitched ? (uint32_t)align_up(d->width, px_bytes == 4 ? 64 : 256) : d->width;
+        pix += align_up((size_t)im->stride * d->height * px_bytes, 256);
         P->total_pixels += (uint64_t)d->width * d->height;
         if (!ok) { /* marked unsupported: no segments, no work-groups, pixels stay zero */
             im->ncomp = 0;

@@ -472,6 +472,65 @@ def test_torch_views_alias_the_output(pkg, dec):
     assert np.array_equal(ragged.tensor(1).cpu().numpy(), ragged.pixels(1))
 
 
+def test_pitched_rows_every_layout(pkg, dec, oracle):
+    """JDGPU_OUT_PITCHED (padded pitch): every row on a 256-byte boundary, the
+    samples those of the dense layout, the padding zero -- ragged widths (whole-dword stores up to
+    the last lane of a row), every sampling layout, gray, restart markers, RGB and YCbCr"""
+    mk = pkg.synth.make_jpeg
+    files = [mk(37, 21, seed=1, quality=80, subsamp=0), mk(130, 17, seed=2, quality=80, subsamp=0),
+             mk(66, 34, seed=3, quality=80, subsamp=1), mk(1, 1, seed=4, quality=80, subsamp=0),
+             mk(258, 9, seed=5, quality=80, subsamp=0), mk(256, 16, seed=6, quality=80, subsamp=1),
+             mk(321, 47, seed=7, quality=70, subsamp=1, restart_mcus=3), mk(90, 50, seed=8, quality=85, subsamp=2),
+             mk(75, 33, seed=9, quality=85, subsamp=3), mk(100, 20, seed=10, quality=85, subsamp=4), mk(52, 40, seed=11, quality=85, subsamp=5),
+             golden_stream("syn_200x136_420_q50"), golden_stream("ex_no_subsampling_lake")]
+    want = []
+    for f in files[:6]:
+        rc, rgb = oracle.rgb(f)
+        assert rc == 0
+        want.append(rgb)
+    for base in (pkg.OUT_RGB, pkg.OUT_YCBCR):
+        for layout, px, unit in ((0, 3, 256), (pkg.OUT_4BYTE, 4, 64), (pkg.OUT_PLANAR, 1, 256)):
+            dense = dec.decode(files, base | layout)
+            out = dec.decode(files, base | layout | pkg.OUT_PITCHED)
+            for i in range(len(files)):
+                assert out.status(i) == 0
+                w, h = out.dims[i]
+                stride = -(-w // unit) * unit
+                assert out.pitch(i) == stride * px and out.pitch(i) % 256 == 0
+                assert out.device_pixels(i) % 256 == 0
+                got = out.pixels(i)
+                assert np.array_equal(got, dense.pixels(i)), (base, layout, i)
+                if base == pkg.OUT_RGB and layout == 0 and i < len(want):
+                    assert np.array_equal(got, want[i]), i
+                # what lies between the rows is zero
+                raw = out.padded(i)
+                planes = 3 if layout == pkg.OUT_PLANAR else 1
+                rows = raw.reshape(planes * h, out.pitch(i))
+                assert rows.size == out.pitch(i) * h * planes
+                assert not rows[:, w * px:].any(), (base, layout, i)
+
+
+def test_pitched_views_and_dlpack(pkg, dec):
+    """zero-copy views of pitched rows (strides through __cuda_array_interface__) and DLPack capsules
+    (SURVEY 8 row f3): same memory, same samples"""
+    import torch
+    files = [pkg.synth.make_jpeg(70, 30, seed=s, quality=85, subsamp=1) for s in (1, 2)]
+    for flags in (pkg.OUT_RGB, pkg.OUT_PLANAR, pkg.OUT_4BYTE, pkg.OUT_RGB | pkg.OUT_PITCHED,
+                  pkg.OUT_PLANAR | pkg.OUT_PITCHED, pkg.OUT_4BYTE | pkg.OUT_PITCHED):
+        out = dec.decode(files, flags)
+        t = out.tensor(1)
+        assert tuple(t.shape) == out.shape(1) and t.data_ptr() == out.device_pixels(1)
+        if flags & pkg.OUT_PITCHED:
+            assert tuple(t.stride()) == out.strides(1) and not t.is_contiguous()
+        assert np.array_equal(t.cpu().numpy(), out.pixels(1))
+        back = torch.from_dlpack(out.dlpack(1))
+        assert back.data_ptr() == t.data_ptr() and tuple(back.shape) == tuple(t.shape)
+        assert tuple(back.stride()) == tuple(t.stride())
+        assert np.array_equal(back.cpu().numpy(), out.pixels(1))
+    with pytest.raises(pkg.JpegError):
+        out.tensor_all()
+
+
 def _with_extra_ac_symbol(data, value):
     """the same stream with one more (never used) symbol of length 16 in the luma AC table: every
     existing code stays what it was, but the table -- and its flattened form -- is a different one"""
