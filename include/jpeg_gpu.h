@@ -80,7 +80,11 @@ enum {
      * jdgpu_batch_pixel_pitch tells it in bytes.  Padding bytes are zero and are never written by a
      * decode.  Combines with every layout above; rows of any width are then stored with whole
      * dwords (the unpadded 3-byte layout goes byte by byte when width % 4 != 0). */
-    JDGPU_OUT_PITCHED = 32
+    JDGPU_OUT_PITCHED = 32,
+    /* the descriptors' `scan` pointers are DEVICE addresses (what jdgpu_parse_files_device leaves in
+     * them): the scans are copied on the device, nothing is staged or uploaded.  The memory they
+     * point into may be released when jdgpu_batch_create returns. */
+    JDGPU_SCAN_ON_DEVICE = 64
 };
 
 /* stages reported by jdgpu_batch_stage_ms */
@@ -124,6 +128,19 @@ int jdgpu_parse_file(const uint8_t *file, size_t len, jdgpu_image_desc *desc);
 long jdgpu_parse_files(const uint8_t *const *files, const size_t *lens, size_t n,
                        jdgpu_image_desc *descs, int *status, unsigned threads);
 
+/* Device-side batched header parsing (row f1 of SURVEY 8): the same marker loop (src/jpeg.c:23-58,
+ * src/parsing.c:13-142) run by a kernel, one lane per file, over n whole files that lie in DEVICE
+ * memory: file i = d_files[offsets[i] .. offsets[i+1]) (offsets: host array of n + 1).  descs and
+ * status are host arrays; the descriptors are byte for byte those of jdgpu_parse_file except that
+ * `scan` is a device address into d_files: hand them to jdgpu_batch_create with
+ * JDGPU_SCAN_ON_DEVICE.  Rejected files: as in jdgpu_parse_files.  One case is not decided by the
+ * kernel: a DHT that assigns more codes than its lengths can hold (the reference's tree builder
+ * wraps and overwrites, src/hufftree.c:46-59; no encoder writes such a table) -- that file is
+ * copied back and goes through jdgpu_parse_file, so the result is the same.  Returns the number
+ * of rejected files or a negative JDGPU_ERR_*. */
+long jdgpu_parse_files_device(const uint8_t *d_files, const uint64_t *offsets, size_t n,
+                              jdgpu_image_desc *descs, int *status);
+
 /* ---- batched decode: replaces jpeg_read_image (src/jpeg.c:63-88) and, with JDGPU_OUT_RGB,
  *      image_ycbcr_to_rgb (src/image.c:39-51), for n independent images ---------------------- */
 
@@ -133,6 +150,13 @@ typedef struct jdgpu_batch jdgpu_batch;
  * uploads scan bytes + tables into HBM and allocates coefficient and pixel buffers.  The
  * descriptors and their scan pointers may be released after this returns. */
 int  jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out);
+/* From whole files in host memory to a batch without the host looking inside them: the files go
+ * through the pinned staging buffer in one upload, the headers are parsed on the device
+ * (jdgpu_parse_files_device), the scans are gathered on the device.  status (may be NULL):
+ * per-file JDGPU_OK / JDGPU_ERR_HEADER; a rejected file is carried as JDGPU_IMG_UNSUPPORTED.
+ * Replaces the caller-side sequence jpeg_read_info + jpeg_read_image of src/test.c:23-32 for n files. */
+int  jdgpu_batch_create_from_files(const uint8_t *const *files, const size_t *lens, size_t n, unsigned flags,
+                                   jdgpu_batch **out, int *status);
 /* Enqueue the whole decode (unstuff, sync, scan, write, pixel kernels) on the batch's stream.
  * Inputs are already resident in HBM; may be called repeatedly. */
 int  jdgpu_batch_decode(jdgpu_batch *b);
@@ -148,6 +172,8 @@ uint64_t jdgpu_batch_total_pixels(const jdgpu_batch *b);            /* sum of wi
 uint64_t jdgpu_batch_total_blocks(const jdgpu_batch *b);            /* 8x8 data units */
 uint64_t jdgpu_batch_total_scan_bytes(const jdgpu_batch *b);
 size_t   jdgpu_batch_image_blocks(const jdgpu_batch *b, size_t i);
+/* width and height of image i as the header gave them (src/jpeg.h:15-16); 0 x 0 for a rejected file */
+int      jdgpu_batch_image_size(const jdgpu_batch *b, size_t i, unsigned *width, unsigned *height);
 /* width*height*3 bytes, layout of `pixel[]` (src/image.h:4-14); with JDGPU_OUT_4BYTE,
  * JDGPU_OUT_PLANAR or JDGPU_OUT_PITCHED the layout chosen at creation, padding included
  * (jdgpu_batch_pixel_bytes tells the size) */

@@ -20,11 +20,12 @@ OK = 0
 ERR_HEADER = -1
 ERR_NO_DEVICE = -10
 IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
-OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR, OUT_PITCHED = 0, 1, 2, 8, 16, 32
+OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR, OUT_PITCHED, SCAN_ON_DEVICE = 0, 1, 2, 8, 16, 32, 64
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 
 EXPORTS = [
     "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_trim", "jdgpu_parse_file", "jdgpu_parse_files",
+    "jdgpu_parse_files_device", "jdgpu_batch_create_from_files", "jdgpu_batch_image_size",
     "jdgpu_batch_create", "jdgpu_batch_decode", "jdgpu_batch_sync", "jdgpu_batch_destroy",
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
@@ -87,6 +88,10 @@ def lib():
                                     C.POINTER(C.c_int), C.c_uint]
     L.jdgpu_parse_files.restype = C.c_long
     L.jdgpu_batch_create.argtypes = [C.POINTER(ImageDesc), sz, C.c_uint, C.POINTER(vp)]
+    L.jdgpu_parse_files_device.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(ImageDesc), C.POINTER(C.c_int)]
+    L.jdgpu_parse_files_device.restype = C.c_long
+    L.jdgpu_batch_create_from_files.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_uint, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.jdgpu_batch_image_size.argtypes = [vp, sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     for f in ("jdgpu_batch_decode", "jdgpu_batch_sync"):
         getattr(L, f).argtypes = [vp]
     L.jdgpu_batch_destroy.argtypes = [vp]
@@ -194,8 +199,47 @@ def parse_many(files, threads=0, strict=True):
     return DescArray(arr, n, keep, list(status[:n]))
 
 
+def parse_device(dev_ptr, offsets, keep=None):
+    """jdgpu_parse_files_device: headers of len(offsets) - 1 files that lie in device memory from
+    dev_ptr (file i = bytes offsets[i] .. offsets[i+1]), parsed by a kernel.  Returns a DescArray
+    whose scan pointers are device addresses: Batch(descs, flags | SCAN_ON_DEVICE)."""
+    L = lib()
+    n = len(offsets) - 1
+    offs = (C.c_uint64 * (n + 1))(*[int(o) for o in offsets])
+    arr = (ImageDesc * max(1, n))()
+    status = (C.c_int * max(1, n))()
+    rc = L.jdgpu_parse_files_device(int(dev_ptr), offs, n, arr, status)
+    if rc < 0:
+        raise _err(L, "jdgpu_parse_files_device", rc)
+    return DescArray(arr, n, keep, list(status)[:n])
+
+
 class Batch:
     """A decode batch resident on one GPU (jdgpu_batch)."""
+
+    @classmethod
+    def from_files(cls, files, flags=OUT_RGB):
+        """jdgpu_batch_create_from_files: whole files in, headers parsed on the GPU, scans gathered
+        on the GPU.  self.file_status: per-file 0 / ERR_HEADER."""
+        L = lib()
+        n = len(files)
+        bufs = [np.frombuffer(f, np.uint8) for f in files]
+        ptrs = (C.c_void_p * max(1, n))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, n))(*[b.size for b in bufs])
+        status = (C.c_int * max(1, n))()
+        h = C.c_void_p()
+        rc = L.jdgpu_batch_create_from_files(ptrs, lens, n, flags, C.byref(h), status)
+        if rc:
+            raise _err(L, "jdgpu_batch_create_from_files", rc)
+        self = cls.__new__(cls)
+        self._L, self._h, self.flags, self.n, self.descs = L, h, flags, n, None
+        self.file_status = list(status)[:n]
+        self.dims = []
+        for i in range(n):
+            w, hh = C.c_uint(), C.c_uint()
+            L.jdgpu_batch_image_size(h, i, C.byref(w), C.byref(hh))
+            self.dims.append((w.value, hh.value))
+        return self
 
     def __init__(self, descs, flags=OUT_RGB):
         L = self._L = lib()

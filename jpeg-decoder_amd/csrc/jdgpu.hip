@@ -32,6 +32,7 @@
 #include <cstring>
 #include <ctime>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "jdgpu_internal.h"
@@ -2111,6 +2112,8 @@ static int stage_reserve(size_t bytes) {
     return JDGPU_OK;
 }
 
+#include "jdgpu_headers.inc"   /* device-side header parsing and scan gather (row f1) */
+
 extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out) {
     if (!out || (!descs && n)) { snprintf(g_err, sizeof g_err, "null argument"); return JDGPU_ERR_ARG; }
     *out = nullptr;
@@ -2172,7 +2175,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     for (size_t i = 0; i < n; ++i) b->any_rst |= P.img[i].ncomp && P.img[i].ri_blocks != 0;
     if (trace) { fprintf(stderr, "[jdgpu] device allocations %.1f ms\n", now() - t0); t0 = now(); }
 
-    {
+    if (!(flags & JDGPU_SCAN_ON_DEVICE)) {
         std::lock_guard<std::mutex> lock(g_stage_mu);
         TRY(stage_reserve(P.raw_bytes));
         P.raw = g_stage; P.raw_owned = 0;
@@ -2189,6 +2192,24 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     if (trace) { fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
+    if (flags & JDGPU_SCAN_ON_DEVICE) {
+        /* the scans already lie in device memory (jdgpu_parse_files_device): copied on the device,
+         * and waited for, so that the caller may release the files when this returns */
+        std::vector<uint64_t> src(n ? n : 1);
+        for (size_t i = 0; i < n; ++i) src[i] = (uint64_t)(uintptr_t)descs[i].scan;
+        uint64_t *d_src = nullptr;
+        TRY(dalloc(&d_src, n));
+        hipError_t e = hipMemcpy(d_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream);
+        if (e == hipSuccess && P.n_rwg) {
+            hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, d_src, b->d_raw);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        pool_free(d_src);
+        HIPTRY(e);
+        if (trace) { fprintf(stderr, "[jdgpu] device gather %.1f ms\n", now() - t0); t0 = now(); }
+    }
     /* on the batch's own stream: ordered before its first decode without waiting for other batches */
     HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
     HIPTRY(hipMemsetAsync(b->d_status, 0, (n ? n : 1) * 4, b->stream));
@@ -2402,6 +2423,13 @@ extern "C" int jdgpu_batch_read_pixels(jdgpu_batch *b, size_t i, void *dst) {
 extern "C" size_t jdgpu_batch_pixel_bytes(const jdgpu_batch *b, size_t i) {
     if (!b || i >= b->plan.n) return 0;
     return (size_t)b->plan.img[i].stride * b->plan.img[i].height * b->plan.px_bytes;
+}
+
+extern "C" int jdgpu_batch_image_size(const jdgpu_batch *b, size_t i, unsigned *width, unsigned *height) {
+    if (!b || i >= b->plan.n) return JDGPU_ERR_ARG;
+    if (width) *width = b->plan.img[i].width;
+    if (height) *height = b->plan.img[i].height;
+    return JDGPU_OK;
 }
 
 extern "C" size_t jdgpu_batch_pixel_pitch(const jdgpu_batch *b, size_t i) {

@@ -895,6 +895,126 @@ def test_fill_bytes_stream_equals_its_twin(pkg, dec, manifest):
     assert hashlib.md5(out.rgb(0).tobytes()).hexdigest() == manifest["syn_64x48_420_q85"]["md5_rgb"]
 
 
+def _dht_at(data, cls_id):
+    """offset of the table with class/id byte cls_id inside a DHT segment (its class/id byte)"""
+    at = 2
+    while data[at:at + 2] != b"\xff\xda":
+        ln = int.from_bytes(data[at + 2:at + 4], "big")
+        if data[at:at + 2] == b"\xff\xc4":
+            t = at + 4
+            while t < at + 2 + ln:
+                if data[t] == cls_id:
+                    return t
+                t += 17 + sum(data[t + 1:t + 17])
+        at += 2 + ln
+    raise KeyError(cls_id)
+
+
+def _header_variants(pkg):
+    """fixtures, degenerate files and ~700 seeded corruptions of fixture HEADERS (scans cut to 64 bytes)"""
+    rng = np.random.default_rng(77)
+    bases = [golden_stream(n) for n in all_golden_names()]
+    bases.append(open(os.path.join(ROOT, "tests", "golden", "streams_ext", "fill_bytes_420.jpg"), "rb").read())
+    descs = pkg.parse_many(bases)
+    hdr = [len(b) - d.scan_len for b, d in zip(bases, descs)]
+    files = list(bases) + [b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"\xff\xd8\xff\xff\xff", rng.bytes(300),
+                           bases[0][:hdr[0]], bases[0][:hdr[0] - 1]]
+    base = bases[0]
+    # a table that assigns more codes than its lengths hold (three 1-bit codes): the host parser's tree decides
+    t = _dht_at(base, 0x00)
+    over = bytearray(base)
+    total = sum(over[t + 1:t + 17])
+    assert total >= 6
+    over[t + 1:t + 17] = bytes([3, 1, total - 4] + [0] * 13)
+    files.append(bytes(over))
+    # a prefix-free table of 300 symbols (the descriptor keeps 256), one without symbols, under an unused id
+    big = b"\xff\xc4" + (2 + 17 + 300).to_bytes(2, "big") + bytes([0x13] + [0] * 8 + [200, 100] + [0] * 6) + bytes(range(256)) + bytes(44)
+    none = b"\xff\xc4" + (2 + 17).to_bytes(2, "big") + bytes([0x12] + [0] * 16)
+    files.append(base[:2] + big + none + base[2:])
+    files.append(base[:2] + base[2:hdr[0] - 14] + b"\xff\xc4" + (2 + 17).to_bytes(2, "big") + bytes([0x00] + [0] * 16) +
+                 base[hdr[0] - 14:])     # the luma DC table redefined empty just before SOS: undefined again
+    for k in range(700):
+        j = k % len(bases)
+        g = bytearray(bases[j][:hdr[j] + 64])
+        kind = k % 5
+        if kind == 0:
+            g[int(rng.integers(2, hdr[j]))] = int(rng.integers(256))
+        elif kind == 1:
+            g = g[:int(rng.integers(0, hdr[j] + 10))]
+        elif kind == 2:
+            g[int(rng.integers(2, hdr[j]))] = 0xFF
+        elif kind == 3:
+            for _ in range(3):
+                g[int(rng.integers(2, hdr[j]))] ^= 1 << int(rng.integers(8))
+        else:
+            at = int(rng.integers(2, hdr[j]))
+            g[at:at] = bytes([0xFF] * int(rng.integers(1, 4)))
+        files.append(bytes(g))
+    return files
+
+
+def _desc_bytes(d, base):
+    """a descriptor as bytes, its scan pointer replaced by the scan's offset in the file"""
+    raw = bytearray(bytes(d))
+    off = (d.scan - base) if d.scan else 0
+    raw[0:8] = int(off).to_bytes(8, "little")
+    return bytes(raw)
+
+
+def test_device_header_parse_equals_host_parser(pkg, dec):
+    """jdgpu_parse_files_device (src/jpeg.c:23-58 + src/parsing.c on the GPU): for
+    every fixture, degenerate file and corrupted header the same verdict and byte for byte the
+    descriptor of jdgpu_parse_file; files back to back in device memory, any alignment"""
+    import torch
+    files = _header_variants(pkg)
+    host = pkg.parse_many(files, strict=False)
+    blob = np.frombuffer(b"".join(files), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in files])]).astype(np.uint64)
+    dev_blob = torch.from_numpy(blob.copy()).cuda()
+    got = pkg.parse_device(dev_blob.data_ptr(), offs, keep=dev_blob)
+    assert got.status == host.status
+    n_ok = 0
+    for i, f in enumerate(files):
+        hb = _desc_bytes(host[i], host._keep[i].ctypes.data)
+        gb = _desc_bytes(got[i], dev_blob.data_ptr() + int(offs[i]))
+        assert hb == gb, (i, host.status[i])
+        n_ok += host.status[i] == 0
+    assert 200 < n_ok < len(files) - 200          # the corruptions reach both verdicts
+    # ... and the descriptors decode: scans gathered on the device from unaligned sources
+    sel = [i for i in range(len(files)) if host.status[i] == 0][:40]
+    sub_offs = [int(offs[i]) for i in sel]
+    a = pkg.Batch([host[i] for i in sel]).decode()
+    b = pkg.Batch([got[i] for i in sel], pkg.OUT_RGB | pkg.SCAN_ON_DEVICE).decode()
+    for k in range(len(sel)):
+        assert a.status(k) == b.status(k), (sel[k], sub_offs[k])
+        assert np.array_equal(a.pixels(k), b.pixels(k)), sel[k]
+
+
+def test_batch_from_files_equals_batch_from_descriptors(pkg, dec):
+    """jdgpu_batch_create_from_files: whole files uploaded, headers parsed and scans gathered on the
+    device -- same statuses, coefficients and pixels as the host-parsed batch, rejected files
+    carried as unsupported"""
+    mk = pkg.synth.make_jpeg
+    files = [golden_stream(n) for n in all_golden_names()]
+    files += [mk(333, 77, seed=3, quality=60, subsamp=1, restart_mcus=2), b"garbage", mk(17, 9, seed=4, quality=90, subsamp=0),
+              b"", mk(640, 480, seed=5, quality=85, subsamp=2)]
+    want = pkg.Batch(pkg.parse_many(files, strict=False)).decode()
+    for flags in (pkg.OUT_RGB, pkg.OUT_YCBCR | pkg.OUT_PLANAR | pkg.OUT_PITCHED):
+        ref = want if flags == pkg.OUT_RGB else pkg.Batch(pkg.parse_many(files, strict=False), flags).decode()
+        out = pkg.Batch.from_files(files, flags).decode()
+        assert out.n == len(files) and out.dims == ref.dims
+        bad = [i for i, f in enumerate(files) if f in (b"garbage", b"")]
+        assert [i for i, s in enumerate(out.file_status) if s] == bad
+        for i in range(len(files)):
+            assert out.status(i) == ref.status(i), i
+            if i in bad:
+                assert out.status(i) == pkg.IMG_UNSUPPORTED
+                continue
+            assert np.array_equal(out.qcoef(i), ref.qcoef(i)), i
+            assert np.array_equal(out.pixels(i), ref.pixels(i)), i
+    assert pkg.Batch.from_files([]).decode().n == 0
+
+
 def test_failed_images_have_zero_pixels(pkg, dec, oracle):
     """an image whose entropy decode stops (EOF / no symbol) used to be rendered from
     whatever the recycled coefficient buffer held.  Its pixels are zero now, on fresh and on

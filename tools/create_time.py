@@ -27,3 +27,21 @@ for attempt in ("first", "second"):
           f"scan {b.total_scan_bytes/1e9:.2f} GB; PCIe-inclusive {b.total_pixels/(tc+td)/1e6:.0f} Mpixel/s, "
           f"resident {b.total_pixels/td/1e6:.0f} Mpixel/s")
     b.close()
+# the same from whole files with the headers parsed on the device (jdgpu_batch_create_from_files)
+h = C.c_void_p(); status = (C.c_int * 4096)()
+for attempt in ("first", "second", "third"):
+    t = time.perf_counter()
+    rc = L.jdgpu_batch_create_from_files(ptrs, lens, 4096, pkg.OUT_RGB, C.byref(h), status); tc = time.perf_counter() - t
+    assert rc == 0 and not any(status)
+    L.jdgpu_batch_decode(h); L.jdgpu_batch_sync(h)
+    t = time.perf_counter(); L.jdgpu_batch_decode(h); L.jdgpu_batch_sync(h); td = time.perf_counter() - t
+    px = L.jdgpu_batch_total_pixels(h)
+    print(f"{attempt} from_files: create {tc*1e3:.1f} ms (no host parse); decode {td*1e3:.1f} ms; PCIe-inclusive {px/(tc+td)/1e6:.0f} Mpixel/s")
+    L.jdgpu_batch_destroy(h)
+# device parse alone, files resident
+import torch
+blob = torch.from_numpy(np.concatenate(keep)).cuda()
+offs = np.concatenate([[0], np.cumsum([k.size for k in keep])]).astype(np.uint64)
+for attempt in range(3):
+    t = time.perf_counter(); d = pkg.parse_device(blob.data_ptr(), offs); tt = time.perf_counter() - t
+    print(f"jdgpu_parse_files_device(4096 resident files): {tt*1e3:.2f} ms, {sum(1 for s in d.status if s)} rejected")
