@@ -229,6 +229,15 @@ int jdgpu_ycbcr_to_rgb_noalloc(void *host_pixels, unsigned width, unsigned heigh
  * include/image.h stays host C, this is for callers whose pixels are large) */
 int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height);
 
+/* The text image_print writes to stdout (src/image.c:13-31), formatted on the device into `out`
+ * (row f4 of SURVEY 8; off the decode path: image_print of include/image.h stays host C, this is
+ * for prints of many cells): per printed pixel ESC[48;2;R;G;Bm + pixelWidth spaces, per row
+ * ESC[0m + newline; rows = min(height, maxPrintHeight), columns while x * pixelWidth <
+ * maxPrintWidth.  *len receives the text's size; out == NULL only queries it; a buffer smaller
+ * than the text returns JDGPU_ERR_ARG and leaves it untouched.  No terminating NUL. */
+int jdgpu_image_format(const void *host_pixels, unsigned width, unsigned height, unsigned maxPrintWidth,
+                       unsigned maxPrintHeight, unsigned pixelWidth, char *out, size_t cap, size_t *len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ EXPORTS = [
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_pixel_pitch", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
-    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_rgb_to_ycbcr",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_rgb_to_ycbcr", "jdgpu_image_format",
     "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
@@ -120,6 +120,7 @@ def lib():
     L.jdgpu_ycbcr_to_rgb_noalloc.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_rgb_to_ycbcr.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_segment_bytes.restype = C.c_uint
+    L.jdgpu_image_format.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, sz, C.POINTER(sz)]
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]
     L.jdgpu_batch_debug_segments.restype = C.c_long
     _lib = L
@@ -451,6 +452,23 @@ def rgb_to_ycbcr(img):
     if rc:
         raise _err(L, "jdgpu_rgb_to_ycbcr", rc)
     return out
+
+
+def format_image(img, max_width, max_height, pixel_width):
+    """jdgpu_image_format: the bytes image_print(img, w, h, max_width, max_height, pixel_width)
+    writes to stdout, formatted on the GPU.  img: (h, w, 3) uint8."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    n = C.c_size_t()
+    rc = L.jdgpu_image_format(img.ctypes.data, w, h, max_width, max_height, pixel_width, None, 0, C.byref(n))
+    if rc:
+        raise _err(L, "jdgpu_image_format", rc)
+    out = np.empty(max(1, n.value), np.uint8)
+    rc = L.jdgpu_image_format(img.ctypes.data, w, h, max_width, max_height, pixel_width, out.ctypes.data, n.value, C.byref(n))
+    if rc:
+        raise _err(L, "jdgpu_image_format", rc)
+    return out[:n.value].tobytes()
 
 
 def segment_bytes():

@@ -2539,3 +2539,5 @@ extern "C" int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned he
 extern "C" int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height) {
     return convert_host_pixels(k_rgb_to_ycbcr, "jdgpu_rgb_to_ycbcr", host_pixels, width, height);
 }
+
+#include "jdgpu_print.inc"   /* image_print's text formatted on the device (row f4) */

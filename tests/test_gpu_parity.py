@@ -1015,6 +1015,50 @@ def test_batch_from_files_equals_batch_from_descriptors(pkg, dec):
     assert pkg.Batch.from_files([]).decode().n == 0
 
 
+def _print_text(img, max_w, max_h, pw):
+    """what image_print writes (src/image.c:13-31), stated in Python"""
+    out = []
+    for y in range(min(img.shape[0], max_h)):
+        x = 0
+        while x < img.shape[1] and x * pw < max_w:
+            r, g, b = (int(v) for v in img[y, x])
+            out.append(f"\x1b[48;2;{r};{g};{b}m" + " " * pw)
+            x += 1
+        out.append("\x1b[0m\n")
+    return "".join(out).encode()
+
+
+def test_image_print_text_formatted_on_the_device(pkg, dec, manifest):
+    """jdgpu_image_format (src/image.c:13-31): byte for byte the text of
+    image_print -- against the statement above for every digit count, clipped and empty prints,
+    rows longer than a work-group pass, and against the tail of the demo CLI's stdout, whose md5
+    the unmodified reference pins (tests/golden/manifest.json)"""
+    rng = np.random.default_rng(5)
+    ramp = np.stack([np.arange(256), np.arange(256)[::-1], (np.arange(256) * 7) % 256], -1).astype(np.uint8)[None]
+    cases = [(ramp, 10000, 5, 2), (ramp, 100, 1, 3), (ramp, 101, 1, 3), (ramp, 0, 1, 2), (ramp, 5, 0, 2), (ramp, 7, 1, 0),
+             (rng.integers(0, 256, (37, 1000, 3), dtype=np.uint8), 1500, 30, 2),
+             (rng.integers(0, 256, (300, 3, 3), dtype=np.uint8), 9, 1000, 1),
+             (rng.integers(0, 256, (1, 1, 3), dtype=np.uint8), 1, 1, 1),
+             (rng.integers(0, 256, (1200, 700, 3), dtype=np.uint8), 4000, 1100, 5)]
+    for img, mw, mh, pw in cases:
+        assert pkg.format_image(img, mw, mh, pw) == _print_text(img, mw, mh, pw), (img.shape, mw, mh, pw)
+    # a buffer that is too small is refused and left alone
+    import ctypes as C
+    L, n = pkg.lib(), C.c_size_t()
+    buf = np.full(16, 0x55, np.uint8)
+    assert L.jdgpu_image_format(ramp.ctypes.data, 256, 1, 1000, 1, 2, buf.ctypes.data, 16, C.byref(n)) == -12
+    assert n.value == len(_print_text(ramp, 1000, 1, 2)) and (buf == 0x55).all()
+    # the demo CLI (src/test.c:32 prints with maxPrintWidth 200, every row, 2 spaces per pixel)
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
+    for name in ("ex_birb", "ex_no_subsampling_lake"):
+        path = os.path.join(ROOT, "tests", "golden", "streams", name + ".jpg")
+        r = subprocess.run([exe, path], capture_output=True, timeout=120)
+        assert hashlib.md5(r.stdout).hexdigest() == manifest[name]["md5_cli_stdout"]
+        rgb = dec.decode([open(path, "rb").read()]).rgb(0)
+        text = pkg.format_image(rgb, 200, rgb.shape[0], 2)
+        assert len(text) > 1000 and r.stdout.endswith(text), name
+
+
 def test_failed_images_have_zero_pixels(pkg, dec, oracle):
     """an image whose entropy decode stops (EOF / no symbol) used to be rendered from
     whatever the recycled coefficient buffer held.  Its pixels are zero now, on fresh and on
