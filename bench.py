@@ -253,39 +253,48 @@ def pcie_inclusive(pkg, files, batch_n, n_batches=6, producers=2):
         px = b.total_pixels
         b.close()
     unpipelined = px / min(times[1:]) / 1e6
-    q = queue.Queue(maxsize=2)
-    todo = list(range(n_batches + 2))
-    lock = threading.Lock()
+    def pipelined(make_batch):
+        q = queue.Queue(maxsize=2)
+        todo = list(range(n_batches + 2))
+        lock = threading.Lock()
 
-    def producer():
-        while True:
-            with lock:
-                if not todo:
+        def producer():
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    todo.pop()
+                try:
+                    q.put(make_batch())
+                except Exception as e:  # e.g. out of device memory with too many batches in flight
+                    q.put(e)
                     return
-                todo.pop()
-            try:
-                q.put(pkg.Batch(pkg.parse_many(batch_files)))
-            except Exception as e:  # e.g. out of device memory with too many batches in flight
-                q.put(e)
-                return
 
-    threads = [threading.Thread(target=producer, daemon=True) for _ in range(producers)]
-    for t in threads:
-        t.start()
-    done, pixels, t0 = 0, 0, None
-    while done < n_batches + 2:
-        b = q.get()
-        if isinstance(b, Exception):
-            raise SystemExit(f"pcie_inclusive: a producer failed: {b}")
-        if done == 2:  # two batches of warm-up
-            t0, pixels = time.perf_counter(), 0
-        b.decode()
-        assert not any(b.status(i) for i in (0, b.n // 2, b.n - 1))
-        pixels += b.total_pixels
-        b.close()
-        done += 1
-    el = time.perf_counter() - t0
+        threads = [threading.Thread(target=producer, daemon=True) for _ in range(producers)]
+        for t in threads:
+            t.start()
+        done, pixels, t0 = 0, 0, None
+        while done < n_batches + 2:
+            b = q.get()
+            if isinstance(b, Exception):
+                raise SystemExit(f"pcie_inclusive: a producer failed: {b}")
+            if done == 2:  # two batches of warm-up
+                t0, pixels = time.perf_counter(), 0
+            b.decode()
+            assert not any(b.status(i) for i in (0, b.n // 2, b.n - 1))
+            pixels += b.total_pixels
+            b.close()
+            done += 1
+        el = time.perf_counter() - t0
+        for t in threads:
+            t.join()
+        return pixels, el
+
+    pixels, el = pipelined(lambda: pkg.Batch(pkg.parse_many(batch_files)))
+    # the same with the headers parsed and the scans gathered on the device (row f1): whole files uploaded
+    pixels_d, el_d = pipelined(lambda: pkg.Batch.from_files(batch_files))
     return {"unit": "Mpixel/s", "unpipelined": round(unpipelined, 1), "pipelined": round(pixels / el / 1e6, 1),
+            "pipelined_device_headers": round(pixels_d / el_d / 1e6, 1),
             "producer_threads": producers, "batches": n_batches, "batch": batch_n,
             "ms_per_batch_pipelined": round(el / n_batches * 1e3, 2),
             "ms_per_batch_unpipelined": round(min(times[1:]) * 1e3, 2),
