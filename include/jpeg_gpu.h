@@ -194,8 +194,10 @@ void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);
 int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
 /* HIP-event milliseconds per stage of the most recent decode (needs JDGPU_PROFILE). */
 int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
-/* number of extra repair passes (beyond the built-in rounds) the last decode needed: 0 in the
- * common case, each one costs a host round trip and a second scan/write/pixel pass */
+/* number of extra passes the last decode needed: 0 in the common case; each one costs a host round
+ * trip, the repair rounds again and a scan/write/pixel pass over the images that were left
+ * unfinished (a segment chain still broken, a coefficient beyond the 64-byte unit form) -- the
+ * other images of the batch are not touched again */
 int      jdgpu_batch_retries(const jdgpu_batch *b);
 /* development aid: how many segments the start-state repair listed in each of its rounds during
  * the last decode pass (summed over the images); rounds beyond the built-in number read 0 */

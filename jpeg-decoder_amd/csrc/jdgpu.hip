@@ -1056,7 +1056,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                                                            const int4 *__restrict__ start_dc,
                                                            int16_t *__restrict__ coef,
                                                            uint32_t *__restrict__ status,
-                                                           uint32_t *__restrict__ wide) {
+                                                           uint32_t *__restrict__ wide,
+                                                           const uint32_t *__restrict__ redo /* a later pass: the images to do again; null = all */) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
     /* <4 waves, 6 table slots>: 3 work-groups = 12 waves per CU wide, 4 narrow; <8, 4> (no image of
      * the batch uses more than 4 slots): 2 work-groups = 16 waves per CU wide, 3 = 24 narrow */
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
     /* SPLIT: narrow and wide instantiation run side by side, each on its own images */
-    const bool mine = !SPLIT || ((wide[wg.img] != 0u) != NARROW);
+    const bool mine = (!SPLIT || ((wide[wg.img] != 0u) != NARROW)) && (!redo || redo[wg.img] != 0u);
     if (!__syncthreads_or(wg.seg0 < n_segs && mine)) return;
     const uint32_t lane = threadIdx.x, wlane = lane & 63u, wbase = lane & ~63u;
     const uint32_t seg = wg.seg0 + wlane;
@@ -1538,6 +1539,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                                                uint8_t *__restrict__ pix,
                                                const uint32_t *__restrict__ status,
                                                const uint32_t *__restrict__ wide,   /* per image: 0 = 64-byte units; null: none is */
+                                               const uint32_t *__restrict__ redo,   /* a later pass: the images to do again; null = all */
                                                uint32_t pix_rows) {
     __shared__ __attribute__((aligned(16))) pix_real s_tr[8 * JD_PIX_WAVES * TR_BLK];
     /* sample tiles: per wave one plane per component, 8 rows per vertical sampling factor */
@@ -1558,6 +1560,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
      * the data units it never reached hold whatever the (recycled) coefficient buffer held */
     if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
+    if (redo && redo[wg.img] == 0u) return;   /* finished by an earlier pass */
     const jd_image &im = imgs[wg.img];
     const bool nar = wide != nullptr && wide[wg.img] == 0u;   /* the image's units are in the narrow form (k_huff_write) */
     const uint32_t ub = nar ? JD_NARROW_UNIT : 128u;          /* bytes per unit */
@@ -1925,6 +1928,7 @@ struct jdgpu_batch {
     float ms[JDGPU_NSTAGES];
     std::vector<uint32_t> status;
     int retries;
+    bool redo;       /* the current pass is a repeat: kernels skip the images whose word in the redo list is 0 */
     bool timed;
 };
 
@@ -2126,7 +2130,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     jdgpu_batch *b = new jdgpu_batch();
     memset(static_cast<void *>(&b->plan), 0, sizeof b->plan);
     b->flags = flags;
-    b->stream = nullptr; b->retries = 0; b->timed = false;
+    b->stream = nullptr; b->retries = 0; b->timed = false; b->redo = false;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
@@ -2160,7 +2164,8 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_list, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_list_cnt, (size_t)JD_REPAIR_ROUNDS * (n ? n : 1)));
     TRY(dalloc(&b->d_status, n));
-    TRY(dalloc(&b->d_wide, 2 * (n ? n : 1))); /* second half: where a test sends the flags to lose them */
+    TRY(dalloc(&b->d_wide, 3 * (n ? n : 1))); /* second part: where a test sends the flags to lose them; third: the
+                                                 images a later pass has to do again (redo_of) */
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_rpl, (size_t)P.n_hwg * JD_WG_WAVES));
@@ -2226,13 +2231,19 @@ static bool narrow_units() {
     return narrow;
 }
 
+/* a pass after the first does only the images the first left unfinished (a broken segment chain, a
+ * narrow unit that overflowed): the third part of d_wide holds one word per image, see jdgpu_batch_sync */
+static const uint32_t *redo_of(const jdgpu_batch *b) {
+    return b->redo ? b->d_wide + 2 * (b->plan.n ? b->plan.n : 1) : nullptr;
+}
+
 template <bool OUT_YCBCR, uint32_t MODE, uint32_t FMT>
 static void launch_pixel_mode(jdgpu_batch *b, hipStream_t st) {
     const uint32_t *f = b->plan.pwg_mode_first;
     if (f[MODE + 1] > f[MODE])
         hipLaunchKernelGGL((k_pixel<OUT_YCBCR, MODE, FMT>), dim3(f[MODE + 1] - f[MODE]), dim3(64 * JD_PIX_WAVES), 0, st,
                            b->d_img, b->d_pwg + f[MODE], b->d_coef, b->d_pix, b->d_status, narrow_units() ? b->d_wide : nullptr,
-                           b->plan.pix_rows);
+                           redo_of(b), b->plan.pix_rows);
 }
 template <bool OUT_YCBCR, uint32_t FMT>
 static void launch_pixel_modes(jdgpu_batch *b, hipStream_t st) {
@@ -2263,7 +2274,7 @@ static uint32_t *wide_flags_of(jdgpu_batch *b) {
 static void launch_write(jdgpu_batch *b, hipStream_t st) {
     jd_plan &P = b->plan;
 #define WRITE_ARGS b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, \
-                   b->d_start_dc, b->d_coef, b->d_status, b->d_wide
+                   b->d_start_dc, b->d_coef, b->d_status, b->d_wide, redo_of(b)
     const bool narrow = narrow_units();
     if (P.wwg_waves == JD_WWG_WAVES_BIG) {
         const dim3 grid(P.n_wwg), block(64 * JD_WWG_WAVES_BIG);
@@ -2310,6 +2321,7 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (P.n == 0) return JDGPU_OK;
     const bool prof = (b->flags & JDGPU_PROFILE) != 0;
     b->retries = 0;
+    b->redo = false;
     hipStream_t st = b->stream;
     HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
     HIPCHK(hipMemsetAsync(b->d_wide, 0, P.n * 4, st)); /* set by the light decodes, kept over repair passes */
@@ -2359,7 +2371,18 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
          * image, so this ends), then redo scan + write + pixel */
         ++b->retries;
         hipStream_t s = b->stream;
-        HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, s));
+        /* only the images marked unfinished are done again: they start from a clean status word,
+         * the others keep theirs (and their coefficients and pixels) */
+        {
+            std::vector<uint32_t> redo(P.n), keep(P.n);
+            for (size_t i = 0; i < P.n; ++i) {
+                redo[i] = (st[i] & JDGPU_IMG_UNSYNCED) ? 1u : 0u;
+                keep[i] = redo[i] ? 0u : st[i];
+            }
+            HIPCHK(hipMemcpy(b->d_wide + 2 * P.n, redo.data(), P.n * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(b->d_status, keep.data(), P.n * 4, hipMemcpyHostToDevice));
+            b->redo = true;
+        }
         std::vector<uint32_t> lc(P.n);
         for (uint32_t pass = 0;; ++pass) {
             if (pass > P.n_segs_cap) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
