@@ -1928,6 +1928,9 @@ struct jdgpu_batch {
     float ms[JDGPU_NSTAGES];
     std::vector<uint32_t> status;
     int retries;
+    uint64_t *d_scan_src; /* JDGPU_SCAN_ON_DEVICE: where the scans lie (read by the gather kernel) */
+    uint8_t *d_files; /* jdgpu_batch_create_from_files: the uploaded files, kept until the batch goes (the scan
+                         gather runs on the batch's stream, in front of its first decode) */
     bool redo;       /* the current pass is a repeat: kernels skip the images whose word in the redo list is 0 */
     bool timed;
 };
@@ -2093,7 +2096,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
                     b->d_list_cnt, b->d_status, b->d_wide, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
                     b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_rpl, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg,
-                    b->d_lane_masks};
+                    b->d_lane_masks, b->d_files, b->d_scan_src};
     for (void *p : bufs) pool_free(p);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -2116,6 +2119,10 @@ static int stage_reserve(size_t bytes) {
     return JDGPU_OK;
 }
 
+/* set by jdgpu_batch_create_from_files around its call of jdgpu_batch_create: the device copy of
+ * the files, which the new batch takes over (so that nothing has to wait for the gather kernel) */
+static thread_local uint8_t *g_adopt_files = nullptr;
+
 #include "jdgpu_headers.inc"   /* device-side header parsing and scan gather (row f1) */
 
 extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsigned flags, jdgpu_batch **out) {
@@ -2131,6 +2138,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     memset(static_cast<void *>(&b->plan), 0, sizeof b->plan);
     b->flags = flags;
     b->stream = nullptr; b->retries = 0; b->timed = false; b->redo = false;
+    b->d_files = g_adopt_files; g_adopt_files = nullptr; b->d_scan_src = nullptr;
     b->d_raw = b->d_clean = b->d_pix = nullptr; b->d_img = nullptr; b->d_luts = nullptr;
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
@@ -2202,17 +2210,17 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
          * and waited for, so that the caller may release the files when this returns */
         std::vector<uint64_t> src(n ? n : 1);
         for (size_t i = 0; i < n; ++i) src[i] = (uint64_t)(uintptr_t)descs[i].scan;
-        uint64_t *d_src = nullptr;
-        TRY(dalloc(&d_src, n));
-        hipError_t e = hipMemcpy(d_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream);
-        if (e == hipSuccess && P.n_rwg) {
-            hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, d_src, b->d_raw);
-            e = hipGetLastError();
+        TRY(dalloc(&b->d_scan_src, n));
+        HIPTRY(hipMemcpy(b->d_scan_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+        HIPTRY(hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream));
+        if (P.n_rwg) {
+            hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, b->d_scan_src, b->d_raw);
+            HIPTRY(hipGetLastError());
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        pool_free(d_src);
-        HIPTRY(e);
+        /* waited for unless the batch owns the files (jdgpu_batch_create_from_files): the caller may
+         * release them when this returns.  Owned files stay until the batch goes: the gather is then
+         * simply the first thing on the batch's stream */
+        if (!b->d_files) HIPTRY(hipStreamSynchronize(b->stream));
         if (trace) { fprintf(stderr, "[jdgpu] device gather %.1f ms\n", now() - t0); t0 = now(); }
     }
     /* on the batch's own stream: ordered before its first decode without waiting for other batches */
