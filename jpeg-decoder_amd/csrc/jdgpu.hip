@@ -1555,6 +1555,10 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
     __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
     __shared__ uint2 s_ctab[OUT_YCBCR ? 1 : 512]; /* colour transform terms per Cb / Cr value (ctab_entry) */
+#ifdef JD_PIX_LDS_PAD   /* occupancy experiment: extra LDS per work-group */
+    __shared__ uint32_t s_pad[JD_PIX_LDS_PAD / 4];
+    if (threadIdx.x == 0 && pix_rows == 0xFFFFFFFFu) s_pad[blockIdx.x % (JD_PIX_LDS_PAD / 4)] = 1;
+#endif
 
     const jd_pix_wg wg = wgs[blockIdx.x];
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
