@@ -423,6 +423,14 @@ def test_no_gpu_fails_loudly(pkg):
         pkg.Batch([pkg.parse(golden_stream("syn_8x8_444_q85"))])
     with pytest.raises(pkg.JpegError):
         pkg.ycbcr_to_rgb(np.zeros((2, 2, 3), np.uint8))
+    # the entry points added in round 2 alike: header parsing on the device, batches from files,
+    # the print formatter
+    with pytest.raises(pkg.JpegError, match="no HIP device"):
+        pkg.Batch.from_files([golden_stream("syn_8x8_444_q85")])
+    with pytest.raises(pkg.JpegError, match="no HIP device"):
+        pkg.parse_device(4096, [0, 10])
+    with pytest.raises(pkg.JpegError, match="no HIP device"):
+        pkg.format_image(np.zeros((2, 2, 3), np.uint8), 10, 10, 2)
     exe = os.path.join(ROOT, "jpeg-decoder_amd", "bin", "test")
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "streams", "ex_birb.jpg")], capture_output=True)
     assert r.returncode != 0 and b"no HIP device" in r.stderr
