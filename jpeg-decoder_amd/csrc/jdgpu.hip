@@ -768,8 +768,18 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
 
 /* the (image, first segment) descriptor of this wave, in scalar registers: everything derived
  * from it (image record, stream base) is then read and computed once per wave, not per lane */
+/* Work-groups go to the 8 XCDs round robin (blockIdx.x % 8).  JD_XCD_SWIZZLE (experiment, off): give every
+ * XCD a contiguous eighth of the work list instead, so that its L2 sees one address range */
+__device__ __forceinline__ uint32_t wg_index() {
+#ifdef JD_XCD_SWIZZLE
+    const uint32_t per = gridDim.x >> 3, b = blockIdx.x;
+    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+#else
+    return blockIdx.x;
+#endif
+}
 __device__ __forceinline__ jd_huff_wg wave_desc(const jd_huff_wg *__restrict__ wgs, uint32_t waves) {
-    const jd_huff_wg w = wgs[blockIdx.x * waves + (threadIdx.x >> 6)];
+    const jd_huff_wg w = wgs[wg_index() * waves + (threadIdx.x >> 6)];
     jd_huff_wg u;
     u.img = __builtin_amdgcn_readfirstlane(w.img);
     u.seg0 = __builtin_amdgcn_readfirstlane(w.seg0);
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
     const jd_image &im = imgs[wg.img];
     const uint32_t n_segs = im.n_segs;
     if (!__syncthreads_or(wg.seg0 < n_segs)) return; /* seg_cap is an upper bound: trailing groups are empty */
-    const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
+    const jd_image &im0 = imgs[wgs[wg_index() * JD_WG_WAVES].img];
     stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
     __syncthreads();
     if (wg.seg0 >= n_segs) return;
@@ -895,7 +905,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
     const jd_image &im = imgs[wg.img];
     const uint32_t n_list = min(list_cnt[wg.img], im.n_segs);
     if (!__syncthreads_or(wg.seg0 < n_list)) return; /* the usual case from the second round on */
-    const jd_image &im0 = imgs[wgs[blockIdx.x * JD_WG_WAVES].img];
+    const jd_image &im0 = imgs[wgs[wg_index() * JD_WG_WAVES].img];
     stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
     __syncthreads();
     if (wg.seg0 >= n_list) return;
@@ -1079,7 +1089,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const uint32_t seg = wg.seg0 + wlane;
     const jd_lut *const g_lut = luts + im.lut_off;
     {
-        const jd_image &im0 = imgs[wgs[blockIdx.x * WAVES].img];
+        const jd_image &im0 = imgs[wgs[wg_index() * WAVES].img];
         stage_tables<false>(s_lut, s_blk, luts + im0.lut_off, im0, SLOTS);
     }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
@@ -1560,7 +1570,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     if (threadIdx.x == 0 && pix_rows == 0xFFFFFFFFu) s_pad[blockIdx.x % (JD_PIX_LDS_PAD / 4)] = 1;
 #endif
 
-    const jd_pix_wg wg = wgs[blockIdx.x];
+    const jd_pix_wg wg = wgs[wg_index()];
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
      * the data units it never reached hold whatever the (recycled) coefficient buffer held */
     if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
