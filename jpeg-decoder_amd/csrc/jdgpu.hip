@@ -1508,7 +1508,12 @@ __device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t 
         uint8_t *dst = rows + at * 3u;
         if (aligned) {
             uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+#ifdef JD_PIX_NT   /* experiment: streaming stores for the output */
+            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+            __builtin_nontemporal_store((u3){w[0], w[1], w[2]}, reinterpret_cast<u3 *>(d32));
+#else
             d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];
+#endif
         } else {
             for (uint32_t i = 0; i < npx * 3; ++i) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
