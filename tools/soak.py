@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development aid: randomized parity soak on the GPU box.  N random streams (sizes 1..400, all five
 layouts plus the four with a sampling factor of 4, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
-decoded in batches of 256 in every output layout, each compared with the oracle: status class,
+decoded in batches of 256 in every output layout (dense and pitched rows; every other batch through
+jdgpu_batch_create_from_files), each compared with the oracle: status class,
 coefficients and pixels bit for bit.  usage: soak.py [N] [seed] [max_side, default 400]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +19,9 @@ rng = np.random.default_rng(seed)
 oracle = Oracle()
 dec = pkg.Decoder(0)
 want_bits = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}
-LAYOUTS = ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_4BYTE, lambda a: a[..., :3]), (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0)))
+LAYOUTS = ((pkg.OUT_RGB, lambda a: a), (pkg.OUT_4BYTE, lambda a: a[..., :3]), (pkg.OUT_PLANAR, lambda a: a.transpose(1, 2, 0)),
+           (pkg.OUT_RGB | pkg.OUT_PITCHED, lambda a: a), (pkg.OUT_4BYTE | pkg.OUT_PITCHED, lambda a: a[..., :3]),
+           (pkg.OUT_PLANAR | pkg.OUT_PITCHED, lambda a: a.transpose(1, 2, 0)))
 bad = done = failed_streams = 0
 t0 = time.time()
 while done < N:
@@ -48,8 +51,9 @@ while done < N:
             else: g[pos:pos + 2] = bytes([0xFF, int(rng.integers(256))])
             f = bytes(g)
         files.append(f)
-    flags, view = LAYOUTS[(done // CHUNK) % 3]
-    out = dec.decode(files, flags)
+    flags, view = LAYOUTS[(done // CHUNK) % 6]
+    # every other batch: whole files uploaded, headers parsed and scans gathered on the device
+    out = pkg.Batch.from_files(files, flags).decode() if (done // CHUNK) % 2 else dec.decode(files, flags)
     for i, f in enumerate(files):
         rc, info, qc = oracle.qcoef(f)
         if rc:
