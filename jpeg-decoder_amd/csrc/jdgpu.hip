@@ -604,6 +604,15 @@ struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
 #endif
 #define JD_CP_BITS  (JD_SEG_BITS / (JD_CP + 1u))
 #define JD_CP_NONE  0xFFFFFFFFu
+/* bit position of checkpoint c (c == JD_CP: the end of the segment) */
+__device__ __forceinline__ constexpr uint32_t cp_mark(uint32_t c) {
+#ifdef JD_CP_MARKS
+    constexpr uint32_t m[JD_CP + 1u] = {JD_CP_MARKS, JD_SEG_BITS};
+    return m[c];
+#else
+    return (c + 1u) * JD_CP_BITS;
+#endif
+}
 
 /*
  * Light decode (no coefficient output): from packed start state `in` run to the end of the
@@ -628,7 +637,7 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
     BlkDesc tb = T.blk[b];
 #pragma unroll
     for (uint32_t c = 0; c <= JD_CP; ++c) {
-        const uint32_t mark = (c + 1u) * JD_CP_BITS;
+        const uint32_t mark = cp_mark(c);
         const uint32_t lim = c < JD_CP ? min(valid, mark) : valid;
         while (p < lim) {
             /* one step for any symbol: the lanes at the start of a data unit take their DC symbol here
