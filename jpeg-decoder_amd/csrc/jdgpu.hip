@@ -841,28 +841,41 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
     stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
     __syncthreads();
     if (wg.seg0 >= n_segs) return;
-    const uint32_t seg = wg.seg0 + (threadIdx.x & 63u);
+    /* a lane takes first_span consecutive segments: the first from a guessed start state, the
+     * others from the exit state of the one before -- their start is then right unless the guess
+     * was wrong AND the decode did not find back within a whole segment (~1 % on C3, against
+     * ~30 % for a guess), and they need no overlap decode */
+    const uint32_t span = im.first_span;   /* 1 in small images (jd_plan_build) */
+    uint32_t seg = wg.seg0 + (threadIdx.x & 63u) * span;
     if (seg >= n_segs) return;
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
     const uint8_t *const cimg = clean + im.clean_off;
-    const uint32_t gs = im.seg_off + seg;
-    const uint32_t si = seg_info[gs];
-
-    uint32_t in = 0; /* the true start state of a restart interval */
-    if (!(si & JD_SEG_FIRST)) {
-        const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
-        in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
+    uint32_t prev_exit = 0;
+#pragma unroll 1
+    for (uint32_t h = 0; h < span && seg < n_segs; ++h, ++seg) {
+        const uint32_t gs = im.seg_off + seg;
+        const uint32_t si = seg_info[gs];
+        uint32_t in = 0; /* the true start state of a restart interval */
+        if (!(si & JD_SEG_FIRST)) {
+            if (h == 0) {
+                const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
+                in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
+            } else {
+                in = prev_exit & ~JD_ST_BAD;
+            }
+        }
+        const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
+                                                  cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
+        st_in[gs] = in;
+        st_exit[gs] = r.exit_state;
+        /* with the unit count: did the segment hold an AC coefficient of 8 or more magnitude bits
+         * (|value| >= 128)?  Such an image's units do not fit the write kernel's int8 buffers.  Kept
+         * per checkpoint interval, so that a repair that stops at a checkpoint takes the flags of
+         * the part it did not decode again from the decode that did; k_seg_scan gathers them once
+         * the start states are final (a decode from a wrong start state sees garbage symbols). */
+        cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
+        prev_exit = r.exit_state;
     }
-    const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
-                                              cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
-    st_in[gs] = in;
-    st_exit[gs] = r.exit_state;
-    /* with the unit count: did the segment hold an AC coefficient of 8 or more magnitude bits
-     * (|value| >= 128)?  Such an image's units do not fit the write kernel's int8 buffers.  Kept
-     * per checkpoint interval, so that a repair that stops at a checkpoint takes the flags of
-     * the part it did not decode again from the decode that did; k_seg_scan gathers them once
-     * the start states are final (a decode from a wrong start state sees garbage symbols). */
-    cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);
 }
 
 __global__ __launch_bounds__(JD_WG_SEGS) void k_chain_check(const jd_image *__restrict__ imgs,
@@ -1945,7 +1958,7 @@ struct jdgpu_batch {
     int4 *d_cnt, *d_start_dc, *d_cp_val;
     int2 *d_start_blk;
     int16_t *d_coef;
-    jd_huff_wg *d_hwg, *d_wwg, *d_rpl;
+    jd_huff_wg *d_hwg, *d_wwg, *d_rpl, *d_fwg;
     jd_pix_wg *d_pwg;
     jd_raw_wg *d_rwg;
     uint2 *d_chunk_cnt, *d_chunk_base;
@@ -2124,7 +2137,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
                     b->d_list_cnt, b->d_status, b->d_wide, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
                     b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_rpl, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg,
-                    b->d_lane_masks, b->d_files, b->d_scan_src};
+                    b->d_lane_masks, b->d_files, b->d_scan_src, b->d_fwg};
     for (void *p : bufs) pool_free(p);
     for (auto &e : b->ev) if (e) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -2171,7 +2184,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -2205,6 +2218,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
     TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_rpl, (size_t)P.n_hwg * JD_WG_WAVES));
+    TRY(dalloc(&b->d_fwg, (size_t)P.n_fwg * JD_WG_WAVES));
     TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
     TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * P.wwg_waves));
@@ -2229,6 +2243,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rpl, P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
+    HIPTRY(hipMemcpy(b->d_fwg, P.fwg, (size_t)P.n_fwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
     HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
@@ -2337,7 +2352,7 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
     hipStream_t st = b->stream;
     const dim3 grid(P.n_hwg), block(JD_WG_SEGS);
     if (first_pass)
-        hipLaunchKernelGGL(k_huff_first, grid, block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_hwg,
+        hipLaunchKernelGGL(k_huff_first, dim3(P.n_fwg), block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_fwg,
                            b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     /* chain check + repair; on a later pass (k_huff_write still found a break) the same again */
     HIPCHK(hipMemsetAsync(b->d_list_cnt, 0, (size_t)JD_REPAIR_ROUNDS * P.n * 4, st));

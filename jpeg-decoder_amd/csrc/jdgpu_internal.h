@@ -148,7 +148,7 @@ typedef struct {
     uint8_t  pad_[1];
     uint32_t stride;                /* output pixels from one row to the next: width, or with JDGPU_OUT_PITCHED the
                                        next count that puts every row on a 256-byte boundary */
-    uint32_t pad2_;
+    uint32_t first_span;            /* consecutive segments a lane of k_huff_first takes in this image (1 .. JD_FIRST_SPAN_MAX, jd_plan_build) */
     uint16_t quant[4][64];          /* dequantisation tables re-ordered for the pixel kernel:
                                        index = col*8 + row (column-major natural order) */
 } jd_image; /* keep a multiple of 8 bytes */
@@ -157,6 +157,16 @@ typedef struct {
 typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 segments of image img from seg0;
                                                                    JD_WG_WAVES consecutive entries form a work-group */
 #define JD_WG_WAVES    (JD_WG_SEGS / 64u)
+#ifndef JD_FIRST_SPAN_MAX
+#define JD_FIRST_SPAN_MAX 4u   /* k_huff_first: a lane decodes up to this many consecutive segments -- only the
+                                  first needs a guessed start state (and the overlap decode that guesses it),
+                                  the others continue; jd_plan_build picks the span per batch */
+#endif
+#define JD_FIRST_SLOTS 8192u   /* waves of k_huff_first the chip holds at a time (256 CUs x 4 SIMDs x 8) */
+#ifndef JD_FIRST_SPAN_MIN_SEGS
+#define JD_FIRST_SPAN_MIN_SEGS 384u   /* ... in images of at least this many segments: a small image's last,
+                                         partly filled wave would cost it more than the overlap decodes saved */
+#endif
 #define JD_NO_WAVE     0xFFFFFFFFu                             /* seg0 of a padding entry */
 #ifndef JD_WWG_WAVES_BIG
 #define JD_WWG_WAVES_BIG 8u                                    /* write kernel, batches whose images use ... */
@@ -195,6 +205,7 @@ typedef struct {
     uint32_t n_intervals;    /* total */
     jd_huff_wg *hwg; uint32_t n_hwg;
     jd_huff_wg *rpl;                   /* the hwg waves in the repair kernel's order (n_hwg groups) */
+    jd_huff_wg *fwg; uint32_t n_fwg;   /* k_huff_first: waves of 64 * first_span segments */
     jd_huff_wg *wwg; uint32_t n_wwg;   /* the same waves in work-groups of wwg_waves (write kernel) */
     uint32_t wwg_waves;
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;

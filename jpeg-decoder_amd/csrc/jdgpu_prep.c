@@ -356,8 +356,40 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
          * entry block across the images of a group: the live waves of a late round then sit
          * together in few work-groups instead of one per image (a work-group with a single live
          * wave still holds 17 KB of LDS).  Per 4096 x 1080p sync 7.35 -> 7.15 ms, C4 4.22 -> 3.83 ms. */
-        for (int pass = 0; pass < 3; ++pass) {
+        /* pass 3: the first light kernel, whose lanes take first_span consecutive segments each
+         * (a wave then covers 64 * first_span segments) */
+        for (int pass = 0; pass < 4; ++pass) {
             const uint32_t W = pass == 1 ? P->wwg_waves : JD_WG_WAVES;
+#define SPAN_OF(i) (pass == 3 ? 64u * P->img[i].first_span : 64u)   /* segments per wave */
+            if (pass == 3) {
+                memset(cnt, 0, (n + MAXG + 1) * sizeof *cnt);
+                /* The span: a wave of span s runs ~(s + 0.3) segment times (the overlap decode is the
+                 * 0.3), and the chip holds JD_FIRST_SLOTS waves of this kernel at a time, so the kernel
+                 * lasts ~ceil(waves(s) / slots) * (s + 0.3).  Measured on 4096 x 1080p (713 segments
+                 * each; first pass, ms): s = 1: 6 rounds, 3.45; 2: 3 rounds, 2.95; 3: 2 rounds, 2.8;
+                 * 4: still 2 rounds, 3.9.  A batch that fits the chip at s = 1 stays there (latency). */
+                uint32_t best = 1;
+                {
+                    const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments */
+                    double best_cost = 0;
+                    for (uint32_t s = 1; s <= JD_FIRST_SPAN_MAX; ++s) {
+                        uint64_t w = 0;
+                        for (size_t i = 0; i < n; ++i) {
+                            if (grp[i] < 0) continue;
+                            const uint32_t per = 64u * (P->img[i].seg_cap >= JD_FIRST_SPAN_MIN_SEGS ? s : 1u);
+                            w += (P->img[i].seg_cap + per - 1u) / per;
+                        }
+                        const double cost = (double)((w + JD_FIRST_SLOTS - 1u) / JD_FIRST_SLOTS) * (s + 0.3);
+                        if (s == 1 || cost < best_cost) { best = s; best_cost = cost; }
+                        if (s == 1 && w <= JD_FIRST_SLOTS) break;
+                    }
+                    if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) best = (uint32_t)atoi(fs);
+                }
+                for (size_t i = 0; i < n; ++i) {
+                    P->img[i].first_span = P->img[i].seg_cap >= JD_FIRST_SPAN_MIN_SEGS ? best : 1u;
+                    if (grp[i] >= 0) cnt[grp[i]] += (P->img[i].seg_cap + SPAN_OF(i) - 1u) / SPAN_OF(i);
+                }
+            }
             /* first descriptor of every group, work-group aligned */
             uint32_t total = 0;
             for (uint32_t g = 0; g < MAXG + nsolo; ++g) {
@@ -367,14 +399,18 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
             jd_huff_wg *L = malloc((total ? total : 1) * sizeof *L);
             if (!L) { free(first); free(grp); free(cnt); free(keys); seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
             for (uint32_t k = 0; k < total; ++k) { L[k].img = 0; L[k].seg0 = JD_NO_WAVE; }
-            if (pass < 2 || all_waves < 8192u) { /* small batches: measured slower entry-block-major (C2 2.19 against 1.87 ms) */
-                for (size_t i = 0; i < n; ++i) {
-                    if (grp[i] < 0) continue;
-                    for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += 64) {
-                        uint32_t k = first[grp[i]]++;
-                        L[k].img = (uint32_t)i; L[k].seg0 = sg;
+            if (pass != 2 || all_waves < 8192u) { /* small batches: measured slower entry-block-major (C2 2.19 against 1.87 ms) */
+                /* pass 3: the images whose lanes take several segments first -- their waves run that
+                 * many times as long, and the kernel should not end on them */
+                for (int sweep = pass == 3 ? 0 : 1; sweep < 2; ++sweep)
+                    for (size_t i = 0; i < n; ++i) {
+                        if (grp[i] < 0) continue;
+                        if (pass == 3 && (P->img[i].first_span > 1u) != (sweep == 0)) continue;
+                        for (uint32_t sg = 0; sg < P->img[i].seg_cap; sg += SPAN_OF(i)) {
+                            uint32_t k = first[grp[i]]++;
+                            L[k].img = (uint32_t)i; L[k].seg0 = sg;
+                        }
                     }
-                }
             } else {
                 for (uint32_t e = 0; e < max_waves; ++e)
                     for (size_t i = 0; i < n; ++i) {
@@ -386,7 +422,10 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
             /* padding descriptors name an image of their own work-group (its tables are staged) */
             for (uint32_t k = 0; k < total; ++k)
                 if (L[k].seg0 == JD_NO_WAVE) L[k].img = L[k - k % W].img;
-            if (pass == 1) { P->wwg = L; P->n_wwg = total / W; } else if (pass == 0) { P->hwg = L; P->n_hwg = total / W; } else P->rpl = L;
+            if (pass == 1) { P->wwg = L; P->n_wwg = total / W; }
+            else if (pass == 0) { P->hwg = L; P->n_hwg = total / W; }
+            else if (pass == 2) P->rpl = L;
+            else { P->fwg = L; P->n_fwg = total / W; }
         }
         free(first);
         free(grp); free(cnt);
@@ -413,6 +452,6 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
 unsigned jdgpu_segment_bytes(void) { return JD_SEG_BYTES; }
 
 void jd_plan_free(jd_plan *P) {
-    free(P->img); free(P->luts); if (P->raw_owned) free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg); free(P->rpl);
+    free(P->img); free(P->luts); if (P->raw_owned) free(P->raw); free(P->hwg); free(P->pwg); free(P->rwg); free(P->wwg); free(P->rpl); free(P->fwg);
     memset(P, 0, sizeof *P);
 }

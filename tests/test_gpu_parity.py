@@ -683,6 +683,36 @@ def test_write_group_variants_agree(pkg, dec, oracle):
         _check_against_oracle(pkg, oracle, dec.decode([files[i]]), 0, files[i])
 
 
+def test_first_pass_spans_agree(pkg, dec, oracle):
+    """k_huff_first's lanes take 1..JD_FIRST_SPAN_MAX consecutive segments each (the plan picks the
+    span per batch; forced here with JDGPU_FIRST_SPAN, read when a batch is created).  Images of
+    384 segments and more with and without restart intervals (an interval start inside a lane's
+    span), a ragged last wave, small images that keep span 1 in the same batch, damaged streams:
+    every span gives the oracle's coefficients, pixels and statuses."""
+    files = [pkg.synth.make_jpeg(1920, 1080, seed=310, quality=85, subsamp=1),
+             pkg.synth.make_jpeg(1920, 1080, seed=311, quality=92, subsamp=0, restart_mcus=7),
+             pkg.synth.make_jpeg(1600, 1200, seed=312, quality=88, subsamp=2, restart_mcus=100),
+             pkg.synth.make_jpeg(320, 240, seed=313, quality=90, subsamp=1)]
+    bad = bytearray(files[0]); bad[len(bad) // 2] ^= 0x5A; bad[len(bad) // 2 + 4000] ^= 0xFF
+    files.append(bytes(bad))
+    files.append(files[0][: len(files[0]) * 2 // 3] + b"\xff\xd9")
+    want = []
+    for f in files:
+        rc, info, q = oracle.qcoef(f)
+        want.append((rc, q, oracle.to_rgb(oracle.pixels_from_qcoef(info, q)) if rc == 0 else None))
+    for span in ("1", "2", "3", "4", "7"):
+        os.environ["JDGPU_FIRST_SPAN"] = span
+        try:
+            out = dec.decode(files)
+        finally:
+            del os.environ["JDGPU_FIRST_SPAN"]
+        for i, (rc, q, rgb) in enumerate(want):
+            assert (out.status(i) == 0) == (rc == 0), (span, i, out.status(i), rc)
+            if rc == 0:
+                assert np.array_equal(out.qcoef(i).astype(np.int32), q), (span, i)
+                assert np.array_equal(out.pixels(i), rgb), (span, i)
+
+
 def test_narrow_write_buffers_and_their_safety_net(pkg, oracle):
     """8-wave write groups keep units in int8 buffers unless the light decodes saw an AC value
     of 8 or more magnitude bits in the image.  A batch that mixes both kinds decodes right; and
