@@ -158,7 +158,7 @@ typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 
                                                                    JD_WG_WAVES consecutive entries form a work-group */
 #define JD_WG_WAVES    (JD_WG_SEGS / 64u)
 #ifndef JD_FIRST_SPAN_MAX
-#define JD_FIRST_SPAN_MAX 4u   /* k_huff_first: a lane decodes up to this many consecutive segments -- only the
+#define JD_FIRST_SPAN_MAX 3u   /* k_huff_first: a lane decodes up to this many consecutive segments -- only the
                                   first needs a guessed start state (and the overlap decode that guesses it),
                                   the others continue; jd_plan_build picks the span per batch */
 #endif

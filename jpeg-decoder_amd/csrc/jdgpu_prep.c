@@ -363,26 +363,17 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
 #define SPAN_OF(i) (pass == 3 ? 64u * P->img[i].first_span : 64u)   /* segments per wave */
             if (pass == 3) {
                 memset(cnt, 0, (n + MAXG + 1) * sizeof *cnt);
-                /* The span: a wave of span s runs ~(s + 0.3) segment times (the overlap decode is the
-                 * 0.3), and the chip holds JD_FIRST_SLOTS waves of this kernel at a time, so the kernel
-                 * lasts ~ceil(waves(s) / slots) * (s + 0.3).  Measured on 4096 x 1080p (713 segments
-                 * each; first pass, ms): s = 1: 6 rounds, 3.45; 2: 3 rounds, 2.95; 3: 2 rounds, 2.8;
-                 * 4: still 2 rounds, 3.9.  A batch that fits the chip at s = 1 stays there (latency). */
-                uint32_t best = 1;
+                /* The span, from what was measured (sync stage, ms; 1080p 4:2:0 q85, 713 segments an image;
+                 * spans 1 / 2 / 3): 1024 images 1.82 / 1.78 / 1.80, 2048: 2.87 / 2.65 / 2.57, 3072: 3.93 /
+                 * 3.56 / 3.50, 4096: 4.98 / 4.48 / 4.34 (4: 5.41, 6: 5.95 -- the lanes of a wave then read
+                 * segments `span` apart, and the stream's 64-byte sectors are shared by fewer and fewer of
+                 * them); config 4 2.83 / 2.70 / 2.66, config 5 3.29 / 3.22 / 3.23.  So: 3 once the batch is
+                 * twice the waves the chip holds at span 1, 2 once it is as many, else 1 (a batch that
+                 * does not fill the chip is a matter of latency, and a longer lane is a longer kernel). */
+                uint32_t best = all_waves >= 2u * JD_FIRST_SLOTS ? 3u : all_waves >= JD_FIRST_SLOTS ? 2u : 1u;
+                if (best > JD_FIRST_SPAN_MAX) best = JD_FIRST_SPAN_MAX;
                 {
                     const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments */
-                    double best_cost = 0;
-                    for (uint32_t s = 1; s <= JD_FIRST_SPAN_MAX; ++s) {
-                        uint64_t w = 0;
-                        for (size_t i = 0; i < n; ++i) {
-                            if (grp[i] < 0) continue;
-                            const uint32_t per = 64u * (P->img[i].seg_cap >= JD_FIRST_SPAN_MIN_SEGS ? s : 1u);
-                            w += (P->img[i].seg_cap + per - 1u) / per;
-                        }
-                        const double cost = (double)((w + JD_FIRST_SLOTS - 1u) / JD_FIRST_SLOTS) * (s + 0.3);
-                        if (s == 1 || cost < best_cost) { best = s; best_cost = cost; }
-                        if (s == 1 && w <= JD_FIRST_SLOTS) break;
-                    }
                     if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) best = (uint32_t)atoi(fs);
                 }
                 for (size_t i = 0; i < n; ++i) {
