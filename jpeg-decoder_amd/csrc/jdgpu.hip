@@ -719,6 +719,11 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
 #ifndef JD_OVERLAP
 #define JD_OVERLAP 1024u
 #endif
+#ifndef JD_OVERLAP_SPAN
+#define JD_OVERLAP_SPAN 1536u   /* ... where a lane takes several segments and guesses only for the first: the longer
+                                   guess is paid by a third of the segments (C3 sync: 1024: 4.33, 1536: 4.21, 2048: 4.34,
+                                   3072: 4.29, 4096: 4.48 ms; config 5 3.23 / 3.23 / 3.28 / 3.35 / 3.46) */
+#endif
 __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTables &T, uint32_t p0, uint32_t valid) {
     uint32_t p = p0, k = 0, b = 0;
     R.init(p);
@@ -859,7 +864,8 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
         if (!(si & JD_SEG_FIRST)) {
             if (h == 0) {
                 const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
-                in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > JD_OVERLAP ? pv - JD_OVERLAP : 0u, pv);
+                const uint32_t ov = span > 1u ? JD_OVERLAP_SPAN : JD_OVERLAP;
+                in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > ov ? pv - ov : 0u, pv);
             } else {
                 in = prev_exit & ~JD_ST_BAD;
             }
