@@ -372,12 +372,13 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
                  * does not fill the chip is a matter of latency, and a longer lane is a longer kernel). */
                 uint32_t best = all_waves >= 2u * JD_FIRST_SLOTS ? 3u : all_waves >= JD_FIRST_SLOTS ? 2u : 1u;
                 if (best > JD_FIRST_SPAN_MAX) best = JD_FIRST_SPAN_MAX;
+                uint32_t min_segs = JD_FIRST_SPAN_MIN_SEGS;
                 {
-                    const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments */
-                    if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) best = (uint32_t)atoi(fs);
+                    const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments: "3", or "3all" for images of any size */
+                    if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) { best = (uint32_t)atoi(fs); if (strstr(fs, "all")) min_segs = 0; }
                 }
                 for (size_t i = 0; i < n; ++i) {
-                    P->img[i].first_span = P->img[i].seg_cap >= JD_FIRST_SPAN_MIN_SEGS ? best : 1u;
+                    P->img[i].first_span = P->img[i].seg_cap >= min_segs ? best : 1u;
                     if (grp[i] >= 0) cnt[grp[i]] += (P->img[i].seg_cap + SPAN_OF(i) - 1u) / SPAN_OF(i);
                 }
             }
