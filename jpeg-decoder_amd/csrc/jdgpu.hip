@@ -84,29 +84,32 @@ __host__ __device__ __forceinline__ size_t clean_byte_addr(uint32_t seg, uint32_
  * ========================================================================================== */
 
 struct RawLane {
-    uint32_t b[17];      /* the lane's 16 bytes + the one after */
+    uint32_t w[4];       /* the lane's 16 bytes, little endian */
+    uint32_t nx;         /* the byte after them (0 past the end of the scan) */
     uint32_t n;          /* how many of the 16 exist */
     uint32_t d0;         /* 1 = the first byte is a dropped follower */
 };
 
+/* called by all 256 lanes of a work-group, i0 = 16 bytes per lane in lane order: the byte after a
+ * lane's 16 and the byte before them come from the neighbouring lanes, from memory only at the
+ * ends of a wave */
 __device__ __forceinline__ RawLane raw_lane_load(const uint8_t *raw, uint32_t raw_len, uint32_t i0) {
     RawLane r;
     uint4 v = make_uint4(0, 0, 0, 0);
-    uint32_t nx = 0;
     r.n = i0 < raw_len ? min(16u, raw_len - i0) : 0u;
-    if (r.n) {
-        v = *reinterpret_cast<const uint4 *>(raw + i0);          /* raw regions are 16-B aligned, zero padded */
-        nx = (i0 + 16 < raw_len) ? raw[i0 + 16] : 0u;
-    }
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.b[i] = (w[i >> 2] >> (8 * (i & 3))) & 255u;
-    r.b[16] = nx;
+    if (r.n) v = *reinterpret_cast<const uint4 *>(raw + i0);          /* raw regions are 16-B aligned, zero padded */
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nx = __shfl_down(v.x & 255u, 1);     /* a lane past the end of the scan holds zeros */
+    uint32_t pv = __shfl_up(v.w >> 24, 1);
+    if (lane == 63u) nx = (r.n && i0 + 16 < raw_len) ? raw[i0 + 16] : 0u;
+    if (lane == 0u) pv = (r.n && i0 > 0) ? raw[i0 - 1] : 0u;
+    r.nx = nx;
     /* parity of the 0xFF run that ends right before i0 (bounded walk: >=4 consecutive 0xFF give
      * 16 one-bits in the clean stream, which no Huffman table can decode, so the image fails
      * either way and the parity of a longer run cannot matter) */
     uint32_t run = 0;
-    if (r.n && i0 > 0 && raw[i0 - 1] == 0xFF) {
+    if (r.n && i0 > 0 && pv == 0xFFu) {
         run = 1;
         while (run < 1024u && run < i0 && raw[i0 - 1 - run] == 0xFF) ++run;
     }
@@ -114,23 +117,42 @@ __device__ __forceinline__ RawLane raw_lane_load(const uint8_t *raw, uint32_t ra
     return r;
 }
 
+/* bit 7 of every byte of x that is 0xFF / that is 0xD0..0xD7 (no carry crosses a byte), and those
+ * four bits gathered into bits 0..3 (the products land on distinct bits: no carry either) */
+__device__ __forceinline__ uint32_t bytes_ff(uint32_t x) { return x & 0x80808080u & ((x & 0x7F7F7F7Fu) + 0x01010101u); }
+__device__ __forceinline__ uint32_t bytes_rst(uint32_t x) {
+    const uint32_t y = (x ^ 0xD0D0D0D0u) & 0xF8F8F8F8u;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t gather_bit7(uint32_t t) { return (((t >> 7) * 0x00204081u) >> 21) & 15u; }
+
 /* classification of the lane's bytes: bit i of keep = byte i goes to the clean stream,
- * bit i of mark = byte i is the 0xFF of a restart marker */
+ * bit i of mark = byte i is the 0xFF of a restart marker.
+ * Byte by byte (src/bitstream.c:7-18 and the restart extension), with d = "this byte is a dropped
+ * follower", d of byte 0 = d0:  ff = exists & !d & byte == 0xFF;  mark = ff & use_rst & next byte in
+ * 0xD0..0xD7 (past the end of the scan: zero padding, never a marker);  keep = exists & !d & !mark;
+ * d of the next byte = ff.  A byte is dropped iff an odd number of 0xFF bytes, counted from the last
+ * kept non-0xFF byte, stands right before it -- the "escaped character" problem of text parsers,
+ * solved on the 16-bit mask of 0xFF bytes with one addition: the carry of a run of ones that starts
+ * on an odd bit comes out on the other parity than that of a run that starts on an even bit. */
 __device__ __forceinline__ void raw_lane_classify(const RawLane &r, bool use_rst, uint32_t &keep, uint32_t &mark) {
-    keep = 0; mark = 0;
-    uint32_t d = r.d0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        bool ex = (uint32_t)i < r.n;
-        uint32_t c = r.b[i];
-        bool ff = ex && !d && c == 0xFF;
-        /* b[i+1] past the end of the scan is zero padding, never 0xD0..0xD7 */
-        bool mk = ff && use_rst && r.b[i + 1] >= 0xD0 && r.b[i + 1] <= 0xD7;
-        bool kp = ex && !d && !mk;
-        keep |= (kp ? 1u : 0u) << i;
-        mark |= (mk ? 1u : 0u) << i;
-        d = ff ? 1u : 0u;
+    const uint32_t ex = (1u << r.n) - 1u;   /* n <= 16 */
+    const uint32_t B = (gather_bit7(bytes_ff(r.w[0])) | (gather_bit7(bytes_ff(r.w[1])) << 4) |
+                        (gather_bit7(bytes_ff(r.w[2])) << 8) | (gather_bit7(bytes_ff(r.w[3])) << 12)) & ex;
+    const uint32_t b = B & ~r.d0;                       /* a dropped first byte starts no run */
+    const uint32_t follows = (b << 1) | r.d0;           /* bytes right behind a 0xFF of a run */
+    const uint32_t even = 0x55555555u;
+    const uint32_t odd_starts = b & ~even & ~follows;   /* runs that start on an odd bit */
+    const uint32_t inv = (odd_starts + b) << 1;
+    const uint32_t dropped = (even ^ inv) & follows;
+    mark = 0;
+    if (use_rst) {   /* per image: wave-uniform */
+        const uint32_t R = gather_bit7(bytes_rst(r.w[0])) | (gather_bit7(bytes_rst(r.w[1])) << 4) |
+                           (gather_bit7(bytes_rst(r.w[2])) << 8) | (gather_bit7(bytes_rst(r.w[3])) << 12) |
+                           ((r.nx >= 0xD0u && r.nx <= 0xD7u) ? 1u << 16 : 0u);
+        mark = B & ~dropped & (R >> 1) & ex;
     }
+    keep = ex & ~dropped & ~mark;
 }
 
 /* exclusive prefix sums of (a, b) over the 256 lanes of a work-group; totals in ta, tb */
@@ -339,6 +361,71 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
     const uint32_t *U = ivl_u + im.u_off;
     const uint32_t *S = ivl_seg + im.ivl_off;
     uint8_t *dst = clean + im.clean_off;
+    /* A chunk without a marker (any chunk of an image without restart intervals) is one run, and
+     * all its kept bytes belong to it: the lane drops its few dropped bytes in registers (one
+     * 128-bit byte removal each; a lane has one with probability 1/16 in entropy-coded data) and
+     * stores its bytes with at most four LDS stores at their byte offset (LDS takes any
+     * alignment), instead of 16 conditional byte stores. */
+    if (tb == 0 && cb.y < nI && U[cb.y] <= u_lo && U[cb.y + 1] >= u_hi && u_hi > u_lo) {
+        const uint64_t shift = (uint64_t)S[cb.y] * JD_SEG_BYTES - U[cb.y];
+        const uint64_t pos_a = u_lo + shift, pos_b = u_hi + shift, base = pos_a & ~(uint64_t)15;
+        uint32_t w0 = rv.x, w1 = rv.y, w2 = rv.z, w3 = rv.w;
+        const uint32_t cnt = __popc(keep);
+        uint32_t off = (uint32_t)(pos_a - base) + ea;
+        if (cnt == 16u) {
+            struct __attribute__((packed)) P16 { uint32_t a, b, c, d; } v{w0, w1, w2, w3};
+            __builtin_memcpy(s_stage + off, &v, 16);
+        } else if (cnt) {
+            uint32_t drop = ~keep & ((2u << (31 - __clz((int)keep))) - 1u);   /* below the last kept byte */
+            while (drop) {   /* remove byte p, the highest first: the bytes above it move down by one */
+                const uint32_t p = 31u - (uint32_t)__clz((int)drop);
+                drop &= ~(1u << p);
+                const uint32_t s0 = __builtin_amdgcn_alignbyte(w1, w0, 1), s1 = __builtin_amdgcn_alignbyte(w2, w1, 1),
+                               s2 = __builtin_amdgcn_alignbyte(w3, w2, 1), s3 = w3 >> 8;
+                auto low = [&](uint32_t j) -> uint32_t {   /* the bytes of word j below byte p */
+                    const int c = (int)p - 4 * (int)j;
+                    return c <= 0 ? 0u : c >= 4 ? ~0u : (1u << (8 * c)) - 1u;
+                };
+                const uint32_t m0 = low(0), m1 = low(1), m2 = low(2), m3 = low(3);
+                w0 = (w0 & m0) | (s0 & ~m0); w1 = (w1 & m1) | (s1 & ~m1);
+                w2 = (w2 & m2) | (s2 & ~m2); w3 = (w3 & m3) | (s3 & ~m3);
+            }
+            if (cnt & 8u) {
+                struct __attribute__((packed)) P8 { uint32_t a, b; } v{w0, w1};
+                __builtin_memcpy(s_stage + off, &v, 8);
+                off += 8; w0 = w2; w1 = w3;
+            }
+            if (cnt & 4u) { __builtin_memcpy(s_stage + off, &w0, 4); off += 4; w0 = w1; }
+            if (cnt & 2u) { const uint16_t h = (uint16_t)w0; __builtin_memcpy(s_stage + off, &h, 2); off += 2; w0 >>= 16; }
+            if (cnt & 1u) s_stage[off] = (uint8_t)w0;
+        }
+        __syncthreads();
+        /* The 16-byte pieces of four neighbouring segments share a 64-byte sector of the transposed
+         * stream: four neighbouring lanes take the same piece of segments 4g .. 4g + 3, so that a
+         * store instruction writes whole sectors (lane order: group of four segments, piece, segment) */
+        const uint32_t pieces = (uint32_t)((pos_b - base + 15u) >> 4);
+        const uint64_t G0 = base >> 4;                                   /* first piece, counted from the image's start */
+        const uint32_t grp0 = (uint32_t)(G0 / (JD_SEG_BYTES / 16u)) >> 2;
+        const uint32_t grp1 = (uint32_t)((G0 + pieces - 1u) / (JD_SEG_BYTES / 16u)) >> 2;
+        const uint32_t total = (grp1 - grp0 + 1u) * 4u * (JD_SEG_BYTES / 16u);
+        for (uint32_t t = threadIdx.x; t < total; t += 256) {
+            const uint32_t seg = (grp0 + t / (4u * (JD_SEG_BYTES / 16u))) * 4u + (t & 3u), pc = (t >> 2) % (JD_SEG_BYTES / 16u);
+            const uint64_t G = (uint64_t)seg * (JD_SEG_BYTES / 16u) + pc;
+            if (G < G0 || G >= G0 + pieces) continue;
+            const uint32_t q = (uint32_t)(G - G0);
+            const uint64_t P = G << 4;
+            if (P + 16u > cap) continue;
+            uint8_t *d = dst + clean_byte_addr(seg, pc * 16u);
+            if (P >= pos_a && P + 16u <= pos_b) {
+                *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s_stage + 16u * q);
+            } else {
+                const uint32_t lo = P >= pos_a ? 0u : (uint32_t)(pos_a - P);
+                const uint32_t hi = P + 16u <= pos_b ? 16u : (uint32_t)(pos_b - P);
+                for (uint32_t k = lo; k < hi; ++k) d[k] = s_stage[16u * q + k];
+            }
+        }
+        return;
+    }
     for (uint32_t run = 0; run <= tb; ++run) {
         const uint32_t m_r = cb.y + run;              /* interval of this run */
         if (m_r >= nI) break;                         /* behind the marker that ends the data */
