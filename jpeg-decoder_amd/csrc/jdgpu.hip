@@ -90,14 +90,18 @@ struct RawLane {
     uint32_t d0;         /* 1 = the first byte is a dropped follower */
 };
 
+/* the lane's 16 bytes (raw regions are 16-byte aligned and zero padded) */
+__device__ __forceinline__ uint4 raw_lane_fetch(const uint8_t *raw, uint32_t raw_len, uint32_t i0) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i0 < raw_len) v = *reinterpret_cast<const uint4 *>(raw + i0);
+    return v;
+}
 /* called by all 256 lanes of a work-group, i0 = 16 bytes per lane in lane order: the byte after a
  * lane's 16 and the byte before them come from the neighbouring lanes, from memory only at the
  * ends of a wave */
-__device__ __forceinline__ RawLane raw_lane_load(const uint8_t *raw, uint32_t raw_len, uint32_t i0) {
+__device__ __forceinline__ RawLane raw_lane_load(const uint4 v, const uint8_t *raw, uint32_t raw_len, uint32_t i0) {
     RawLane r;
-    uint4 v = make_uint4(0, 0, 0, 0);
     r.n = i0 < raw_len ? min(16u, raw_len - i0) : 0u;
-    if (r.n) v = *reinterpret_cast<const uint4 *>(raw + i0);          /* raw regions are 16-B aligned, zero padded */
     r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nx = __shfl_down(v.x & 255u, 1);     /* a lane past the end of the scan holds zeros */
@@ -211,22 +215,39 @@ __device__ __forceinline__ void wg_exclusive_scan_packed(uint32_t a, uint32_t b,
     __syncthreads();
 }
 
+/* A work-group takes JD_RAW_PER_WG chunks of the work list, one after the other, and issues the
+ * loads of all of them before it looks at the first: a chunk is one load, a few dozen
+ * instructions, a barrier and one store per lane, so a work-group that takes a single chunk
+ * spends its life waiting for that load, and the chip cannot hold enough of them to cover it. */
 __global__ __launch_bounds__(256) void k_unstuff_count(const jd_image *__restrict__ imgs,
-                                                       const jd_raw_wg *__restrict__ wgs,
+                                                       const jd_raw_wg *__restrict__ wgs, uint32_t n_wgs,
                                                        const uint8_t *__restrict__ raw,
                                                        uint2 *__restrict__ chunk_cnt,
                                                        uint32_t *__restrict__ lane_masks) {
     __shared__ uint32_t s_tmp[8];
-    const jd_raw_wg wg = wgs[blockIdx.x];
-    const jd_image &im = imgs[wg.img];
-    RawLane r = raw_lane_load(raw + im.raw_off, im.raw_len, wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
-    uint32_t keep, mark;
-    raw_lane_classify(r, im.ri_blocks != 0, keep, mark);
-    /* the classification is kept for k_unstuff_marks / k_unstuff_scatter (4 bytes per 16 of the scan) */
-    lane_masks[(size_t)blockIdx.x * 256u + threadIdx.x] = keep | (mark << 16);
-    uint32_t ea, eb, ta, tb;
-    wg_exclusive_scan_packed(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
-    if (threadIdx.x == 0) chunk_cnt[im.chunk_off + wg.chunk] = make_uint2(ta, tb);
+    jd_raw_wg wg[JD_RAW_PER_WG];
+    uint4 v[JD_RAW_PER_WG];
+#pragma unroll
+    for (uint32_t e = 0; e < JD_RAW_PER_WG; ++e) {
+        const uint32_t idx = blockIdx.x * JD_RAW_PER_WG + e;
+        wg[e] = wgs[min(idx, n_wgs - 1u)];
+        const jd_image &im = imgs[wg[e].img];
+        v[e] = raw_lane_fetch(raw + im.raw_off, idx < n_wgs ? im.raw_len : 0u, wg[e].chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < JD_RAW_PER_WG; ++e) {
+        const uint32_t idx = blockIdx.x * JD_RAW_PER_WG + e;
+        if (idx >= n_wgs) break;   /* the same for the whole work-group */
+        const jd_image &im = imgs[wg[e].img];
+        RawLane r = raw_lane_load(v[e], raw + im.raw_off, im.raw_len, wg[e].chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+        uint32_t keep, mark;
+        raw_lane_classify(r, im.ri_blocks != 0, keep, mark);
+        /* the classification is kept for k_unstuff_marks / k_unstuff_scatter (4 bytes per 16 of the scan) */
+        lane_masks[(size_t)idx * 256u + threadIdx.x] = keep | (mark << 16);
+        uint32_t ea, eb, ta, tb;
+        wg_exclusive_scan_packed(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
+        if (threadIdx.x == 0) chunk_cnt[im.chunk_off + wg[e].chunk] = make_uint2(ta, tb);
+    }
 }
 
 /* one work-group per image: chunk_base = exclusive scan of chunk_cnt; U[0] = 0 and, when the
@@ -332,25 +353,11 @@ __global__ __launch_bounds__(256) void k_unstuff_layout(jd_image *__restrict__ i
  * chunk (one, unless markers fall inside it) the bytes are first compacted in LDS at the byte
  * alignment of their destination, then stored 16 bytes per lane; only the ragged first and last
  * 16 bytes of a run are stored byte by byte (the neighbouring chunk fills in the rest). */
-__global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restrict__ imgs,
-                                                         const jd_raw_wg *__restrict__ wgs,
-                                                         const uint8_t *__restrict__ raw,
-                                                         const uint2 *__restrict__ chunk_base,
-                                                         const uint32_t *__restrict__ ivl_u,
-                                                         const uint32_t *__restrict__ ivl_seg,
-                                                         const uint32_t *__restrict__ lane_masks,
-                                                         uint8_t *__restrict__ clean) {
-    __shared__ uint32_t s_tmp[8];
-    __shared__ __align__(16) uint8_t s_stage[JD_RAW_CHUNK + 32];
-    const jd_raw_wg wg = wgs[blockIdx.x];
-    const jd_image &im = imgs[wg.img];
-    const uint32_t km = lane_masks[(size_t)blockIdx.x * 256u + threadIdx.x];
+__device__ __forceinline__ void scatter_chunk(const jd_image &im, const jd_raw_wg wg, const uint32_t km, const uint4 rv,
+                                              const uint2 *__restrict__ chunk_base, const uint32_t *__restrict__ ivl_u,
+                                              const uint32_t *__restrict__ ivl_seg, uint8_t *__restrict__ clean,
+                                              uint32_t *s_tmp, uint8_t *s_stage) {
     const uint32_t keep = km & 0xFFFFu, mark = km >> 16;
-    uint4 rv = make_uint4(0, 0, 0, 0);   /* the lane's 16 bytes (raw regions are 16-byte aligned and zero padded) */
-    {
-        const uint32_t i0 = wg.chunk * JD_RAW_CHUNK + threadIdx.x * 16u;
-        if (i0 < im.raw_len) rv = *reinterpret_cast<const uint4 *>(raw + im.raw_off + i0);
-    }
     const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
     uint32_t ea, eb, ta, tb;
     wg_exclusive_scan_packed(__popc(keep), __popc(mark), s_tmp, ea, eb, ta, tb);
@@ -461,6 +468,36 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
             }
         }
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restrict__ imgs,
+                                                         const jd_raw_wg *__restrict__ wgs, uint32_t n_wgs,
+                                                         const uint8_t *__restrict__ raw,
+                                                         const uint2 *__restrict__ chunk_base,
+                                                         const uint32_t *__restrict__ ivl_u,
+                                                         const uint32_t *__restrict__ ivl_seg,
+                                                         const uint32_t *__restrict__ lane_masks,
+                                                         uint8_t *__restrict__ clean) {
+    __shared__ uint32_t s_tmp[8];
+    __shared__ __align__(16) uint8_t s_stage[JD_RAW_CHUNK + 32];
+    jd_raw_wg wg[JD_RAW_PER_WG];
+    uint4 rv[JD_RAW_PER_WG];
+    uint32_t km[JD_RAW_PER_WG];
+    /* all loads first (see k_unstuff_count) */
+#pragma unroll
+    for (uint32_t e = 0; e < JD_RAW_PER_WG; ++e) {
+        const uint32_t idx = min(blockIdx.x * JD_RAW_PER_WG + e, n_wgs - 1u);
+        wg[e] = wgs[idx];
+        const jd_image &im = imgs[wg[e].img];
+        km[e] = lane_masks[(size_t)idx * 256u + threadIdx.x];
+        rv[e] = raw_lane_fetch(raw + im.raw_off, im.raw_len, wg[e].chunk * JD_RAW_CHUNK + threadIdx.x * 16u);
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < JD_RAW_PER_WG; ++e) {
+        if (blockIdx.x * JD_RAW_PER_WG + e >= n_wgs) break;   /* the same for the whole work-group */
+        if (e) __syncthreads();   /* the staging buffer is free again */
+        scatter_chunk(imgs[wg[e].img], wg[e], km[e], rv[e], chunk_base, ivl_u, ivl_seg, clean, s_tmp, s_stage);
     }
 }
 
@@ -2472,14 +2509,14 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
     if (P.n_rwg) {
         HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
-        hipLaunchKernelGGL(k_unstuff_count, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_cnt, b->d_lane_masks);
+        hipLaunchKernelGGL(k_unstuff_count, dim3((P.n_rwg + JD_RAW_PER_WG - 1u) / JD_RAW_PER_WG), dim3(256), 0, st, b->d_img, b->d_rwg, P.n_rwg, b->d_raw, b->d_chunk_cnt, b->d_lane_masks);
         hipLaunchKernelGGL(k_unstuff_chunks, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u);
         if (b->any_rst)
             hipLaunchKernelGGL(k_unstuff_marks, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_cnt,
                                b->d_chunk_base, b->d_lane_masks, b->d_ivl_u);
         hipLaunchKernelGGL(k_unstuff_layout, dim3((unsigned)P.n), dim3(256), 0, st, b->d_img, b->d_ivl_u, b->d_ivl_seg,
                            b->d_seg_info, b->d_clean);
-        hipLaunchKernelGGL(k_unstuff_scatter, dim3(P.n_rwg), dim3(256), 0, st, b->d_img, b->d_rwg, b->d_raw, b->d_chunk_base,
+        hipLaunchKernelGGL(k_unstuff_scatter, dim3((P.n_rwg + JD_RAW_PER_WG - 1u) / JD_RAW_PER_WG), dim3(256), 0, st, b->d_img, b->d_rwg, P.n_rwg, b->d_raw, b->d_chunk_base,
                            b->d_ivl_u, b->d_ivl_seg, b->d_lane_masks, b->d_clean);
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[1], st));
