@@ -141,6 +141,7 @@ def hooks():
                                             C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         H.jdgpu_host_unstuff.argtypes = [u8p, sz, C.c_uint, C.c_uint, u8p, sz, C.POINTER(C.c_uint32), sz]
         H.jdgpu_host_unstuff.restype = C.c_long
+        H.jdgpu_host_plan_first_list.argtypes = [C.POINTER(ImageDesc), sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _hooks = H
     return _hooks
 

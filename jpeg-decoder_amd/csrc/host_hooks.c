@@ -11,6 +11,7 @@
 #include "host_hooks.h"
 #include "jdgpu_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 /* ---- host statement of the unstuff stage --------------------------------------------------------
@@ -71,3 +72,32 @@ long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsig
     return (long)jd_unstuff_image(scan, len, (int)use_rst, n_intervals ? n_intervals : 1, clean, seg_info);
 }
 
+
+/* Builds the batch plan for the descriptors and checks the work list of k_huff_first: every image's
+ * segments [0, seg_cap) are covered exactly once by waves of 64 * first_span segments, padding
+ * entries carry JD_NO_WAVE.  span[i] = the image's first_span (0 for an image the plan rejects),
+ * *n_waves = live entries of the list.  0 ok, -1 plan failed, -2 list broken. */
+int jdgpu_host_plan_first_list(const jdgpu_image_desc *descs, size_t n, uint32_t *span, uint32_t *n_waves) {
+    jd_plan P;
+    char err[128];
+    if (jd_plan_build(descs, n, 3u, 0u, &P, err, sizeof err) != JDGPU_OK) return -1;
+    int rc = 0;
+    uint32_t *next = calloc(n ? n : 1, sizeof *next), live = 0;
+    if (!next) { jd_plan_free(&P); return -1; }
+    for (size_t i = 0; i < n; ++i) span[i] = P.img[i].ncomp ? P.img[i].first_span : 0u;
+    for (uint32_t k = 0; k < P.n_fwg * JD_WG_WAVES && rc == 0; ++k) {
+        const jd_huff_wg w = P.fwg[k];
+        if (w.img >= n) { rc = -2; break; }
+        if (w.seg0 == JD_NO_WAVE) continue;
+        ++live;
+        /* the waves of an image come in order, each where the one before ended */
+        if (!P.img[w.img].ncomp || w.seg0 != next[w.img] || w.seg0 >= P.img[w.img].seg_cap) rc = -2;
+        next[w.img] = w.seg0 + 64u * P.img[w.img].first_span;
+    }
+    for (size_t i = 0; i < n && rc == 0; ++i)
+        if (P.img[i].ncomp && next[i] < P.img[i].seg_cap) rc = -2;
+    *n_waves = live;
+    free(next);
+    jd_plan_free(&P);
+    return rc;
+}

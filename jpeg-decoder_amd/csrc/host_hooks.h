@@ -24,6 +24,11 @@ int  jdgpu_host_lut_lookup(const jdgpu_huff_spec *spec, int is_dc, unsigned v16,
 long jdgpu_host_unstuff(const uint8_t *scan, size_t len, unsigned use_rst, unsigned n_intervals,
                         uint8_t *clean, size_t clean_cap, uint32_t *seg_info, size_t seg_cap);
 
+/* batch plan of the descriptors: checks the work list of k_huff_first (every segment of every image
+ * covered once by waves of 64 * span segments); span[i] = the span the plan gave image i,
+ * *n_waves = waves on the list.  0 ok, -1 no plan, -2 list broken */
+int  jdgpu_host_plan_first_list(const jdgpu_image_desc *descs, size_t n, uint32_t *span, uint32_t *n_waves);
+
 #ifdef __cplusplus
 }
 #endif

@@ -577,3 +577,42 @@ def test_factor_four_layouts_are_planned(pkg):
                      ("syn_80x96_2x4_q90", (2, 4))):
         d = pkg.parse(golden_stream(name))
         assert (d.comp[0].H, d.comp[0].V) == hv and (d.comp[1].H, d.comp[1].V) == (1, 1)
+
+
+def test_first_pass_work_list_and_span_rule(pkg):
+    """k_huff_first's work list (jd_plan::fwg): a lane takes `span` consecutive segments, a wave 64 *
+    span.  The plan picks the span per batch -- 1 while the batch does not fill the chip's 8192 wave
+    slots at one segment per lane, 2 from there, 3 from twice that -- and only for images of 384
+    segments and more; whatever it picks, every segment of every image is on the list exactly
+    once (checked in C by the test-only hook, csrc/host_hooks.c).  JDGPU_FIRST_SPAN forces a span."""
+    import ctypes as C
+    H = pkg.hooks()
+    big = pkg.synth.make_jpeg(1920, 1080, seed=5, quality=85, subsamp=1)
+    rst = pkg.synth.make_jpeg(1920, 1080, seed=6, quality=85, subsamp=1, restart_mcus=120)
+    small = pkg.synth.make_jpeg(320, 240, seed=7, quality=85, subsamp=0)
+    d3 = pkg.parse_many([big, rst, small])
+    sb = pkg.segment_bytes()
+    waves_big = -(-(-(-d3[0].scan_len // sb)) // 64)   # an upper bound of the stream's segments, in waves
+
+    def plan(descs):
+        n = len(descs)
+        arr = (pkg.ImageDesc * n)(*descs)
+        span = (C.c_uint32 * n)()
+        waves = C.c_uint32()
+        rc = H.jdgpu_host_plan_first_list(arr, n, span, C.byref(waves))
+        assert rc == 0, rc
+        return list(span), waves.value
+
+    for copies, want in ((8, 1), (8192 // waves_big + 8, 2), (2 * 8192 // waves_big + 16, 3)):
+        span, waves = plan([d3[i % 2] for i in range(copies)] + [d3[2]])
+        assert set(span[:-1]) == {want}, (copies, span[:4])
+        assert span[-1] == 1                      # the small image keeps one segment per lane
+        assert waves >= copies * (waves_big // want) // 2
+    for forced in ("1", "2", "5", "3all"):
+        os.environ["JDGPU_FIRST_SPAN"] = forced
+        try:
+            span, _ = plan([d3[0], d3[1], d3[2]] * 3)
+        finally:
+            del os.environ["JDGPU_FIRST_SPAN"]
+        f = int(forced.rstrip("al"))
+        assert span[0] == span[1] == f and span[2] == (f if forced.endswith("all") else 1)
