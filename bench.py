@@ -373,6 +373,10 @@ def main():
             "roofline": with_traffic(roof(dominant), args.workload, args.layout, res["pixels_rank"]),
             "pixel_stage": with_traffic(roof("pixel"), args.workload, args.layout, res["pixels_rank"]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            # every stage against the HBM roofline by its ALGORITHMIC bytes (DESIGN.md section 4
+            # says what each stage is really bound by: only the pixel stage is a bandwidth kernel)
+            "stage_rooflines": {s: {"achieved_GBps": roof(s)["achieved"], "frac": roof(s)["frac"]}
+                                for s in ("unstuff", "sync", "write", "pixel")},
             "stitch_retries": res["retries"],
         }
         if git_head():
