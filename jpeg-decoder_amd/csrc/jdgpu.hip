@@ -1206,7 +1206,12 @@ __device__ __forceinline__ uint32_t wbuf_key(uint32_t lane) {
  * tell, `wide`).  The wide instantiation is launched beside it and takes the other images; each
  * skips the waves that are not its own. */
 __device__ __forceinline__ uint32_t nbuf_key(uint32_t lane) { return lane * 64u + ((lane & 7u) << 3); } /* address = idx ^ key */
-template <uint32_t WAVES, uint32_t SLOTS, bool NARROW, bool SPLIT>
+/* SUB = JD_CP + 1 (small batches, jd_plan::write_sub): SUB lanes per segment.  Lane q > 0 starts where
+ * the light decodes recorded checkpoint q - 1 -- state, and data units / DC differences counted up to
+ * there (cp_state, cp_val: final once the chain of start states is) -- and owns the units that start
+ * before checkpoint q; lane 0 those before checkpoint 0.  The write stage of a batch that leaves the
+ * chip idle is as long as one lane's chain of symbols: a quarter of it this way. */
+template <uint32_t WAVES, uint32_t SLOTS, bool NARROW, bool SPLIT, uint32_t SUB = 1u>
 __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__restrict__ imgs,
                                                            const jd_lut *__restrict__ luts,
                                                            const uint8_t *__restrict__ clean,
@@ -1219,8 +1224,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                                                            int16_t *__restrict__ coef,
                                                            uint32_t *__restrict__ status,
                                                            uint32_t *__restrict__ wide,
-                                                           const uint32_t *__restrict__ redo /* a later pass: the images to do again; null = all */) {
+                                                           const uint32_t *__restrict__ redo /* a later pass: the images to do again; null = all */,
+                                                           const uint32_t *__restrict__ cp_state,
+                                                           const int4 *__restrict__ cp_val) {
     static_assert(JD_SEG_BITS >= 2048, "a data unit (<= 64 * 26 bits) must fit in one segment");
+    static_assert(SUB == 1u || SUB == JD_CP + 1u, "one lane per segment, or one per checkpoint interval");
     /* <4 waves, 6 table slots>: 3 work-groups = 12 waves per CU wide, 4 narrow; <8, 4> (no image of
      * the batch uses more than 4 slots): 2 work-groups = 16 waves per CU wide, 3 = 24 narrow */
     __shared__ __attribute__((aligned(16))) jd_lut_hot s_lut[SLOTS];
@@ -1238,7 +1246,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const bool mine = (!SPLIT || ((wide[wg.img] != 0u) != NARROW)) && (!redo || redo[wg.img] != 0u);
     if (!__syncthreads_or(wg.seg0 < n_segs && mine)) return;
     const uint32_t lane = threadIdx.x, wlane = lane & 63u, wbase = lane & ~63u;
-    const uint32_t seg = wg.seg0 + wlane;
+    const uint32_t seg = wg.seg0 + wlane / SUB, sub = wlane % SUB;
     const jd_lut *const g_lut = luts + im.lut_off;
     {
         const jd_image &im0 = imgs[wgs[wg_index() * WAVES].img];
@@ -1269,8 +1277,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     uint32_t flags = 0;
     /* chain check: the state this segment starts from must be the one its predecessor ended in
      * (it is not when a correction crossed a whole work-group: the host then stitches again) */
-    if (active && !first && seg > 0 && ((st_exit[gs - 1] ^ in) & ~JD_ST_BAD)) flags |= JDGPU_IMG_UNSYNCED;
-    if (active && first && in != 0) flags |= JDGPU_IMG_UNSYNCED;
+    if (active && sub == 0u && !first && seg > 0 && ((st_exit[gs - 1] ^ in) & ~JD_ST_BAD)) flags |= JDGPU_IMG_UNSYNCED;
+    if (active && sub == 0u && first && in != 0) flags |= JDGPU_IMG_UNSYNCED;
 
     const int2 sb = start_blk[gs];
     const int4 sd = start_dc[gs];
@@ -1279,8 +1287,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     int pr0 = sd.x, pr1 = sd.y, pr2 = sd.z;
 
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
+    uint32_t vend = valid;      /* units that start before this bit are the lane's */
+    bool last_sub = true;       /* the lane that reaches the end of the segment's data */
+    if (SUB > 1u) {
+        const uint32_t *cs = cp_state + (size_t)gs * JD_CP;
+        const int4 *cv = cp_val + (size_t)gs * (JD_CP + 1u);
+        if (sub > 0u) {
+            const uint32_t st = cs[sub - 1u];
+            if (st == JD_CP_NONE) active = false;   /* the segment ends before this lane's checkpoint */
+            else { p = st & 0xFFFFu; k = (st >> 16) & 255u; b = st >> 24; }
+            for (uint32_t i = 0; i < sub; ++i) {
+                const int4 v = cv[i];
+                B += v.x & (JD_CNT_WIDE - 1); pr0 += v.y; pr1 += v.z; pr2 += v.w;
+            }
+        }
+        if (sub + 1u < SUB) {
+            const uint32_t nx = cs[sub];
+            if (nx != JD_CP_NONE) { vend = min(valid, nx & 0xFFFFu); last_sub = false; }
+        }
+    }
     BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
-    R.init(p);
+    R.init(active ? p : 0u);
     const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), g_lut, s_blk, 0u};
     BlkDesc tb = s_blk[b];
     bool own = (k == 0); /* does this lane own the data unit it is in? */
@@ -1295,7 +1322,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const uint32_t dcmask = dc_on & 0xFFu, topmask = top_on & 0xFF000000u;
 
     /* a unit is decoded while it STARTED before the end of the segment */
-    active = active && (k != 0 || p < valid) && B < limit;
+    active = active && (k != 0 || p < vend) && B < limit;
     /* Everything the loop reads that came from memory is "used" here, so that the compiler waits
      * for those loads BEFORE the loop.  gfx9 counts loads and stores in one in-order counter: a
      * wait for a pre-loop load placed inside the loop is a wait for all but the newest few memory
@@ -1347,7 +1374,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 finished = end && own;
                 fB = B;
                 B += end ? 1 : 0; own = own || end; k = end ? 0u : k; b = end ? nb : b;
-                active = ok && (k != 0 || p < valid) && B < limit;
+                active = ok && (k != 0 || p < vend) && B < limit;
             }
         }
         tb = s_blk[b]; /* once per iteration, all lanes: no divergent merge copies the descriptor around */
@@ -1408,7 +1435,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
         }
     }
     /* data ended before the interval's data units did */
-    if (!flags && seg < n_segs && B < limit && is_last) flags |= JDGPU_IMG_EOF;
+    if (!flags && seg < n_segs && B < limit && is_last && last_sub && (SUB == 1u || sub == 0u || cp_state[(size_t)gs * JD_CP + sub - 1u] != JD_CP_NONE))
+        flags |= JDGPU_IMG_EOF;
     if (NARROW && ((ovf & ~255u) | ovf2)) { /* safety net: mark the image wide and have the host run the pass again */
         atomicOr(&wide[wg.img], 1u);
         flags |= JDGPU_IMG_UNSYNCED;
@@ -2455,7 +2483,7 @@ static uint32_t *wide_flags_of(jdgpu_batch *b) {
 static void launch_write(jdgpu_batch *b, hipStream_t st) {
     jd_plan &P = b->plan;
 #define WRITE_ARGS b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_wwg, b->d_st_in, b->d_st_exit, b->d_start_blk, \
-                   b->d_start_dc, b->d_coef, b->d_status, b->d_wide, redo_of(b)
+                   b->d_start_dc, b->d_coef, b->d_status, b->d_wide, redo_of(b), b->d_cp_state, b->d_cp_val
     const bool narrow = narrow_units();
     if (P.wwg_waves == JD_WWG_WAVES_BIG) {
         const dim3 grid(P.n_wwg), block(64 * JD_WWG_WAVES_BIG);
@@ -2467,7 +2495,14 @@ static void launch_write(jdgpu_batch *b, hipStream_t st) {
         }
     } else {
         const dim3 grid(P.n_wwg), block(64 * JD_WG_WAVES);
-        if (narrow) { /* 35 instead of 51 KB per work-group: 4 instead of 3 per CU */
+        if (P.write_sub > 1u) { /* a small batch: JD_CP + 1 lanes per segment */
+            if (narrow) {
+                hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, true, true, JD_CP + 1u>), grid, block, 0, st, WRITE_ARGS);
+                hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, false, true, JD_CP + 1u>), grid, block, 0, st, WRITE_ARGS);
+            } else {
+                hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, false, false, JD_CP + 1u>), grid, block, 0, st, WRITE_ARGS);
+            }
+        } else if (narrow) { /* 35 instead of 51 KB per work-group: 4 instead of 3 per CU */
             hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, true, true>), grid, block, 0, st, WRITE_ARGS);
             hipLaunchKernelGGL((k_huff_write<JD_WG_WAVES, JD_LUT_SLOTS, false, true>), grid, block, 0, st, WRITE_ARGS);
         } else {

@@ -162,6 +162,12 @@ typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 
                                   first needs a guessed start state (and the overlap decode that guesses it),
                                   the others continue; jd_plan_build picks the span per batch */
 #endif
+#ifndef JD_CP
+#define JD_CP 3u    /* checkpoints inside a segment (jdgpu.hip: decode_light) */
+#endif
+#ifndef JD_WRITE_SUB_MAX_WAVES
+#define JD_WRITE_SUB_MAX_WAVES 2560u   /* a batch of at most this many 64-segment waves has its segments written by JD_CP + 1 lanes each */
+#endif
 #define JD_FIRST_SLOTS 8192u   /* waves of k_huff_first the chip holds at a time (256 CUs x 4 SIMDs x 8) */
 #ifndef JD_FIRST_SPAN_MIN_SEGS
 #define JD_FIRST_SPAN_MIN_SEGS 384u   /* ... in images of at least this many segments: a small image's last,
@@ -212,6 +218,7 @@ typedef struct {
     jd_huff_wg *fwg; uint32_t n_fwg;   /* k_huff_first: waves of 64 * first_span segments */
     jd_huff_wg *wwg; uint32_t n_wwg;   /* the same waves in work-groups of wwg_waves (write kernel) */
     uint32_t wwg_waves;
+    uint32_t write_sub;                /* lanes of k_huff_write per segment: 1, or JD_CP + 1 in a small batch */
     jd_pix_wg *pwg;  uint32_t n_pwg; uint32_t pix_rows;
     uint32_t pwg_mode_first[JD_PIX_MODES + 1]; /* pwg is grouped by jd_image::pix_mode: [first[m], first[m+1]) */
     jd_raw_wg *rwg;  uint32_t n_rwg;

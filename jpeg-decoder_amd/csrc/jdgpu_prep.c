@@ -358,30 +358,38 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
          * wave still holds 17 KB of LDS).  Per 4096 x 1080p sync 7.35 -> 7.15 ms, C4 4.22 -> 3.83 ms. */
         /* pass 3: the first light kernel, whose lanes take first_span consecutive segments each
          * (a wave then covers 64 * first_span segments) */
+        {
+            /* The span, from what was measured (sync stage, ms; 1080p 4:2:0 q85, 713 segments an image;
+             * spans 1 / 2 / 3): 1024 images 1.82 / 1.78 / 1.80, 2048: 2.87 / 2.65 / 2.57, 3072: 3.93 /
+             * 3.56 / 3.50, 4096: 4.98 / 4.48 / 4.34 (4: 5.41, 6: 5.95 -- the lanes of a wave then read
+             * segments `span` apart, and the stream's 64-byte sectors are shared by fewer and fewer of
+             * them); config 4 2.83 / 2.70 / 2.66, config 5 3.29 / 3.22 / 3.23.  So: 3 once the batch is
+             * twice the waves the chip holds at span 1, 2 once it is as many, else 1 (a batch that
+             * does not fill the chip is a matter of latency, and a longer lane is a longer kernel). */
+            uint32_t best = all_waves >= 2u * JD_FIRST_SLOTS ? 3u : all_waves >= JD_FIRST_SLOTS ? 2u : 1u;
+            if (best > JD_FIRST_SPAN_MAX) best = JD_FIRST_SPAN_MAX;
+            uint32_t min_segs = JD_FIRST_SPAN_MIN_SEGS;
+            {
+                const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments: "3", or "3all" for images of any size */
+                if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) { best = (uint32_t)atoi(fs); if (strstr(fs, "all")) min_segs = 0; }
+            }
+            for (size_t i = 0; i < n; ++i) P->img[i].first_span = P->img[i].seg_cap >= min_segs ? best : 1u;
+        }
+        /* The write kernel of a batch that leaves most of the chip idle (thumbnails, a single image)
+         * is the latency of one lane's decode of a whole segment: there a segment is written by
+         * JD_CP + 1 lanes, lane q from the state the light decodes recorded at checkpoint q - 1
+         * (k_huff_write<.., SUB>), and a wave covers 64 / (JD_CP + 1) segments. */
+        {
+            const char *ws = getenv("JDGPU_WRITE_SUB");   /* tests and experiments: "1" / "4" */
+            P->write_sub = (P->wwg_waves == JD_WG_WAVES && all_waves <= JD_WRITE_SUB_MAX_WAVES) ? JD_CP + 1u : 1u;
+            if (ws && P->wwg_waves == JD_WG_WAVES) P->write_sub = atoi(ws) == 1 ? 1u : JD_CP + 1u;
+        }
         for (int pass = 0; pass < 4; ++pass) {
             const uint32_t W = pass == 1 ? P->wwg_waves : JD_WG_WAVES;
-#define SPAN_OF(i) (pass == 3 ? 64u * P->img[i].first_span : 64u)   /* segments per wave */
-            if (pass == 3) {
-                memset(cnt, 0, (n + MAXG + 1) * sizeof *cnt);
-                /* The span, from what was measured (sync stage, ms; 1080p 4:2:0 q85, 713 segments an image;
-                 * spans 1 / 2 / 3): 1024 images 1.82 / 1.78 / 1.80, 2048: 2.87 / 2.65 / 2.57, 3072: 3.93 /
-                 * 3.56 / 3.50, 4096: 4.98 / 4.48 / 4.34 (4: 5.41, 6: 5.95 -- the lanes of a wave then read
-                 * segments `span` apart, and the stream's 64-byte sectors are shared by fewer and fewer of
-                 * them); config 4 2.83 / 2.70 / 2.66, config 5 3.29 / 3.22 / 3.23.  So: 3 once the batch is
-                 * twice the waves the chip holds at span 1, 2 once it is as many, else 1 (a batch that
-                 * does not fill the chip is a matter of latency, and a longer lane is a longer kernel). */
-                uint32_t best = all_waves >= 2u * JD_FIRST_SLOTS ? 3u : all_waves >= JD_FIRST_SLOTS ? 2u : 1u;
-                if (best > JD_FIRST_SPAN_MAX) best = JD_FIRST_SPAN_MAX;
-                uint32_t min_segs = JD_FIRST_SPAN_MIN_SEGS;
-                {
-                    const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments: "3", or "3all" for images of any size */
-                    if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) { best = (uint32_t)atoi(fs); if (strstr(fs, "all")) min_segs = 0; }
-                }
-                for (size_t i = 0; i < n; ++i) {
-                    P->img[i].first_span = P->img[i].seg_cap >= min_segs ? best : 1u;
-                    if (grp[i] >= 0) cnt[grp[i]] += (P->img[i].seg_cap + SPAN_OF(i) - 1u) / SPAN_OF(i);
-                }
-            }
+#define SPAN_OF(i) (pass == 3 ? 64u * P->img[i].first_span : pass == 1 ? 64u / P->write_sub : 64u)   /* segments per wave */
+            memset(cnt, 0, (n + MAXG + 1) * sizeof *cnt);
+            for (size_t i = 0; i < n; ++i)
+                if (grp[i] >= 0) cnt[grp[i]] += (P->img[i].seg_cap + SPAN_OF(i) - 1u) / SPAN_OF(i);
             /* first descriptor of every group, work-group aligned */
             uint32_t total = 0;
             for (uint32_t g = 0; g < MAXG + nsolo; ++g) {

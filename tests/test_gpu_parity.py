@@ -713,6 +713,39 @@ def test_first_pass_spans_agree(pkg, dec, oracle):
                 assert np.array_equal(out.pixels(i), rgb), (span, i)
 
 
+def test_write_lanes_per_segment_agree(pkg, dec, oracle):
+    """A small batch has every segment written by JD_CP + 1 lanes, each from the state the light
+    decodes recorded at a checkpoint (jd_plan::write_sub; forced either way with JDGPU_WRITE_SUB,
+    read when a batch is created).  One lane and four lanes per segment give identical statuses,
+    coefficients and pixels on intact, damaged and truncated streams, with restart intervals shorter
+    and longer than a segment, and both equal the oracle."""
+    files = fuzzed_streams(oracle, count=60)
+    files += [pkg.synth.make_jpeg(640, 480, seed=400 + s, quality=(35, 75, 92, 100)[s % 4], subsamp=s % 5,
+                                  restart_mcus=(0, 3, 40, 700)[s % 4]) for s in range(12)]
+    files.append(pkg.synth.make_jpeg(1920, 1080, seed=420, quality=85, subsamp=1))
+    got = {}
+    for sub in ("1", "4"):
+        os.environ["JDGPU_WRITE_SUB"] = sub
+        try:
+            out = dec.decode(files)
+        finally:
+            del os.environ["JDGPU_WRITE_SUB"]
+        got[sub] = [(out.status(i), out.qcoef(i) if out.status(i) == 0 else None, out.pixels(i) if out.status(i) == 0 else None)
+                    for i in range(len(files))]
+    n_ok = 0
+    for i, (a, b) in enumerate(zip(got["1"], got["4"])):
+        rc, info, q = oracle.qcoef(files[i])
+        assert (a[0] == 0) == (b[0] == 0) == (rc == 0), (i, a[0], b[0], rc)
+        if rc == 0:
+            n_ok += 1
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), i
+            assert np.array_equal(b[1].astype(np.int32), q), i
+        else:
+            want = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}[rc]
+            assert a[0] & want and b[0] & want, (i, rc, a[0], b[0])
+    assert n_ok >= 20
+
+
 def test_narrow_write_buffers_and_their_safety_net(pkg, oracle):
     """8-wave write groups keep units in int8 buffers unless the light decodes saw an AC value
     of 8 or more magnitude bits in the image.  A batch that mixes both kinds decodes right; and
