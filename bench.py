@@ -20,12 +20,24 @@ restatement -- timed on ONE pinned host core over a bounded sample of the same w
 the same on all the cores this process may use (`all_cores`).  At N = 1 the default run adds
 `pcie_inclusive` (host files -> parse -> create -> decode, pipelined and not) and
 `other_workloads` (short runs of the other BASELINE configs); --lean leaves them out.
+
+`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) starts the N ranks itself:
+N fresh child processes of the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+before this process has touched torch or HIP; it relays rank 0's JSON line and exits non-zero if a
+child does.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks are the launcher's; --gpus must then equal WORLD_SIZE.
+
+`verified`: after the timed steps (outside them) every copy of every distinct stream is compared on
+the device with the first copy of that stream, and one copy each of up to 8 distinct streams with
+the CPU oracle's coefficients and RGB (oracle/ used as the checker, like in the cpu_baseline leg);
+a mismatch ends the run with a non-zero exit status.
 """
 import argparse
 import itertools
 import json
 import os
 import queue
+import socket
 import subprocess
 import sys
 import threading
@@ -143,10 +155,73 @@ def cpu_baseline(files, budget_s=10.0, all_cores_budget_s=8.0):
 
 # ---- timed decode of one workload ----------------------------------------------------------------
 
-def run_workload(pkg, torch, dist, name, batch_n, distinct, steps, warmup, layout, world, rank, rehearsal):
+def verify_outputs(pkg, torch, batch, idx, files, n_oracle=8):
+    """What the timed steps left in HBM, checked after them (outside the timed region): every copy of
+    distinct stream k against the first copy of k on the device (torch.equal over the output views),
+    and the LAST copy of up to n_oracle distinct streams against the CPU oracle: quantised coefficients
+    bit for bit, RGB to the north star's +-1 (observed: 0).  This covers the plan choices only the
+    full-size batches trigger (spans, 8-wave write groups at 4096 x 1080p, config 4 at 512)."""
+    from oracle.oracle import Oracle
+    torch.cuda.synchronize()
+    first, last, bad_copies, compared = {}, {}, 0, 0
+    for i, k in enumerate(idx):
+        last[k] = i
+        if k not in first:
+            first[k] = (i, batch.tensor(i))
+            continue
+        compared += 1
+        if not torch.equal(batch.tensor(i), first[k][1]):
+            bad_copies += 1
+    o = Oracle()
+    ks = sorted(first)[:n_oracle]
+    bad_oracle, max_d = 0, 0
+    for k in ks:
+        i = last[k]
+        rc, _info, q = o.qcoef(files[k], honour_dri=True)
+        rc2, want = o.rgb(files[k], honour_dri=True)
+        if rc or rc2:
+            bad_oracle += 1
+            continue
+        d = int(np.abs(batch.pixels(i).astype(np.int16) - want.astype(np.int16)).max())
+        max_d = max(max_d, d)
+        if d > 1 or not np.array_equal(batch.qcoef(i), q.astype(np.int16)):
+            bad_oracle += 1
+    return {"images": len(idx), "copies_equal_on_device": compared - bad_copies, "copies_compared": compared,
+            "vs_oracle": len(ks), "vs_oracle_mismatches": bad_oracle, "max_abs_rgb_diff": max_d,
+            "ok": bad_copies == 0 and bad_oracle == 0}
+
+
+def reduce_ranks(torch, dist, elapsed, pixels_rank, world, rank, on_cpu):
+    """max-over-ranks time and every rank's pixel count (the only cross-rank traffic of the path)"""
+    per_rank = [pixels_rank]
+    if dist is not None:
+        dev = "cpu" if on_cpu else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.zeros(world, dtype=torch.float64, device=dev)
+        p[rank] = float(pixels_rank)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        per_rank = [int(x) for x in p.tolist()]
+    return elapsed, per_rank
+
+
+def run_workload(pkg, torch, dist, name, batch_n, distinct, steps, warmup, layout, world, rank, rehearsal,
+                 verify=True, dry_run=False):
     files = make_files(pkg, name, distinct)
     descs = pkg.parse_many(files)
     idx = batch_indices(pkg, name, descs, batch_n, world, rank)
+    if dry_run:
+        # JD_BENCH_DRYRUN=1 (CPU test of the launcher and the N > 1 control flow): everything but the GPU --
+        # files, header parse, this rank's shard, the rendezvous and the reductions
+        pixels_rank = sum(descs[i].width * descs[i].height for i in idx)
+        if dist is not None:
+            dist.barrier()
+        elapsed, per_rank = reduce_ranks(torch, dist, 1.0 + rank, pixels_rank, world, rank, True)
+        return {"files": files, "elapsed": elapsed, "pixels_rank": pixels_rank, "pixels_per_rank": per_rank,
+                "stage_ms": {k: 0.0 for k in pkg.STAGES}, "retries": 0, "blocks": 0,
+                "scan_bytes": sum(descs[i].scan_len for i in idx), "n": len(idx), "distinct": len(files),
+                "verified": None}
     layout_flag = {"rgb": 0, "rgba": pkg.OUT_4BYTE, "planar": pkg.OUT_PLANAR, "rgb-pitched": pkg.OUT_PITCHED,
                    "rgba-pitched": pkg.OUT_4BYTE | pkg.OUT_PITCHED, "planar-pitched": pkg.OUT_PLANAR | pkg.OUT_PITCHED}[layout]
     batch = pkg.Batch([descs[i] for i in idx], flags=pkg.OUT_RGB | pkg.PROFILE | layout_flag)
@@ -157,10 +232,11 @@ def run_workload(pkg, torch, dist, name, batch_n, distinct, steps, warmup, layou
             dist.barrier()
         torch.cuda.synchronize()
 
+    ablation = bool(os.environ.get("JD_BENCH_ABLATION"))  # ablation builds decode garbage on purpose
     for _ in range(warmup):
         batch.decode()
     for i in range(batch.n):
-        if batch.status(i) and not os.environ.get("JD_BENCH_ABLATION"):  # ablation builds decode garbage on purpose
+        if batch.status(i) and not ablation:
             raise SystemExit(f"{name}: image {i} failed to decode: status {batch.status(i)}")
     stage_sum = {}
     barrier()
@@ -172,19 +248,16 @@ def run_workload(pkg, torch, dist, name, batch_n, distinct, steps, warmup, layou
     barrier()
     elapsed = time.perf_counter() - t0
     pixels_rank = batch.total_pixels
-    per_rank = [pixels_rank]
-    if dist is not None:
-        dev = "cpu" if rehearsal else "cuda"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        p = torch.zeros(world, dtype=torch.float64, device=dev)
-        p[rank] = float(pixels_rank)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        per_rank = [int(x) for x in p.tolist()]
+    elapsed, per_rank = reduce_ranks(torch, dist, elapsed, pixels_rank, world, rank, rehearsal)
+    verified = None
+    if verify and layout == "rgb" and not ablation:
+        verified = verify_outputs(pkg, torch, batch, idx, files)
+        if not verified["ok"]:
+            raise SystemExit(f"{name}: the decoded batch FAILED verification: {json.dumps(verified)}")
     res = {"files": files, "elapsed": elapsed, "pixels_rank": pixels_rank, "pixels_per_rank": per_rank,
            "stage_ms": {k: v / steps for k, v in stage_sum.items()}, "retries": batch.retries,
-           "blocks": batch.total_blocks, "scan_bytes": batch.total_scan_bytes, "n": batch.n, "distinct": len(files)}
+           "blocks": batch.total_blocks, "scan_bytes": batch.total_scan_bytes, "n": batch.n, "distinct": len(files),
+           "verified": verified}
     batch.close()
     return res
 
@@ -227,6 +300,11 @@ def with_traffic(r, workload, layout, pixels):
         if workload == "c3" and layout == "rgb" and k:
             per_px = (2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024 / (t["images"] * t["pixels_per_image"])
             r["traffic"] = int(per_px * pixels)
+            # how busy HBM really is: the bytes the kernel moves (narrow images keep 64-byte units, so
+            # fewer than SURVEY's algorithmic bytes) over the same live-measured duration
+            if r["avg_ms"] > 0:
+                r["achieved_measured"] = round(r["traffic"] / (r["avg_ms"] * 1e-3) / 1e9, 1)
+                r["frac_measured"] = round(r["achieved_measured"] / HBM_PEAK_GBS, 4)
             r["traffic_source"] = (f"{os.path.relpath(path, ROOT)} (kernels at commit {t.get('kernel_commit', 'unrecorded')}): "
                                    "PMC FETCH_SIZE x2 + WRITE_SIZE (KiB), 256-image launch, scaled per pixel; "
                                    "not a counter read of this run")
@@ -309,6 +387,51 @@ def git_head():
         return None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this
+    same command line (this process has not imported torch or touched HIP and never does), one per GPU,
+    rendezvous on 127.0.0.1.  Rank 0's stdout (the JSON line) is relayed; the others' goes to stderr.
+    Returns the exit status: non-zero if any rank's is."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's pipe is drained by a thread; the ranks are polled, so that one that dies does not leave the
+    # others waiting in a rendezvous or a barrier for their time-outs: they are ended (by PID) at once
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(c is not None for c in rcs):
+            break
+        if any(c for c in rcs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    reader.join(30)
+    sys.stdout.write(b"".join(chunks).decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit status): {bad}", file=sys.stderr)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,38 +441,53 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the decoded batch after the timed steps")
     ap.add_argument("--lean", action="store_true", help="headline workload only: no pcie_inclusive, no other_workloads")
     ap.add_argument("--layout", default="rgb", choices=["rgb", "rgba", "planar", "rgb-pitched", "rgba-pitched", "planar-pitched"],
                     help="output layout (default: the reference's 3-byte pixel[]; the others are SURVEY 8 row f3)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: "
+                         "give both the same number (or leave the launcher out: bench.py starts its own ranks)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("JD_BENCH_FAIL_RANK") == str(rank):   # test hook: a rank that dies before the rendezvous
+        raise SystemExit(f"rank {rank}: JD_BENCH_FAIL_RANK")
     import torch
     dist = None
     # JD_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the N > 1 control flow
-    # on a one-GPU box (the real N > 1 run is one rank per GPU over RCCL)
-    rehearsal = bool(os.environ.get("JD_BENCH_REHEARSAL"))
+    # on a one-GPU box (the real N > 1 run is one rank per GPU over RCCL).  JD_BENCH_DRYRUN=1: no GPU
+    # at all (tests/test_multi_rank.py: launcher, rendezvous, sharding, reductions, JSON line)
+    dry_run = bool(os.environ.get("JD_BENCH_DRYRUN"))
+    rehearsal = bool(os.environ.get("JD_BENCH_REHEARSAL")) or dry_run
     if rehearsal:
         local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        if not dry_run:
+            torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
-    pkg.Decoder(local_rank)
+    if not dry_run:
+        pkg.Decoder(local_rank)
     desc, batch_n, distinct = WORKLOADS[args.workload]
     batch_n = args.batch or batch_n
     distinct = min(args.distinct or distinct, batch_n)
     px_bytes = 4 if args.layout.startswith("rgba") else 3
 
     res = run_workload(pkg, torch, dist, args.workload, batch_n, distinct, args.steps, args.warmup, args.layout,
-                       world, rank, rehearsal)
+                       world, rank, rehearsal, verify=not args.no_verify, dry_run=dry_run)
 
     if rank == 0:
         K = args.steps
@@ -360,7 +498,7 @@ def main():
         stage_ms = res["stage_ms"]
         dominant = max((s for s in alg if s != "scan"), key=lambda s: stage_ms.get(s, 0.0))
         out = {
-            "metric": "decoded Mpixels/s", "value": round(value, 1), "unit": "Mpixel/s",
+            "metric": "decoded Mpixels/s", "value": None if dry_run else round(value, 1), "unit": "Mpixel/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 entropy decode, f64 IDCT", "data": "synthetic",
@@ -378,10 +516,13 @@ def main():
             "stage_rooflines": {s: {"achieved_GBps": roof(s)["achieved"], "frac": roof(s)["frac"]}
                                 for s in ("unstuff", "sync", "write", "pixel")},
             "stitch_retries": res["retries"],
+            "verified": res["verified"],
         }
+        if dry_run:
+            out["dry_run"] = True
         if git_head():
             out["commit"] = git_head()
-        extras = world == 1 and not args.lean and args.workload == "c3" and not args.batch
+        extras = world == 1 and not args.lean and args.workload == "c3" and not args.batch and not dry_run
         if extras:
             pkg.trim()
             out["pcie_inclusive"] = pcie_inclusive(pkg, res["files"], batch_n)
@@ -389,22 +530,23 @@ def main():
             others = {}
             for name in ("c2", "c4", "c5"):
                 d2, b2, n2 = WORKLOADS[name]
-                r2 = run_workload(pkg, torch, None, name, b2, n2, 5, 2, "rgb", 1, 0, False)
+                r2 = run_workload(pkg, torch, None, name, b2, n2, 5, 2, "rgb", 1, 0, False, verify=not args.no_verify)
                 _, roof2 = stage_rooflines(r2, 3)
                 others[name] = {"workload": d2, "batch": r2["n"], "value": round(r2["pixels_rank"] / (r2["elapsed"] / 5) / 1e6, 1),
                                 "unit": "Mpixel/s", "ms_per_step": round(r2["elapsed"] / 5 * 1e3, 3), "steps": 5, "warmup": 2,
                                 "stage_ms": {k: round(v, 4) for k, v in r2["stage_ms"].items()},
-                                "pixel_stage_frac_of_hbm_peak": roof2("pixel")["frac"], "stitch_retries": r2["retries"]}
+                                "pixel_stage_frac_of_hbm_peak": roof2("pixel")["frac"], "stitch_retries": r2["retries"],
+                                "verified": r2["verified"]}
                 pkg.trim()
             out["other_workloads"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry_run:
             cpu_files = res["files"]
             if args.workload == "c4":  # the reference aborts on DRI (src/jpeg.c:50): same pixels, no DRI
                 cpu_files = [pkg.synth.make_jpeg(3840, 2160, seed=4321 + i, quality=85, subsamp=1) for i in range(2)]
             out["cpu_baseline"] = cpu_baseline(cpu_files)
             if out["cpu_baseline"]["value"]:
                 out["gpu_over_cpu_core"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -64,3 +64,54 @@ def test_greedy_is_deterministic_and_complete():
     loads = [sum(costs[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= max(costs)
     assert parts == [sh.shard_greedy(costs, 8, r) for r in range(8)]
+
+
+def _bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the command line the driver uses for N = 1,
+    with another N): two child ranks, a rendezvous over 127.0.0.1, each rank's own shard of the global
+    config-5 list, ONE JSON line from rank 0 with n_gpus = 2 and both ranks' pixel counts.
+    JD_BENCH_DRYRUN leaves out the GPU only."""
+    r, out = _bench(["--gpus", "2", "--workload", "c5", "--batch", "48", "--distinct", "12", "--steps", "1", "--warmup", "0"],
+                    {"JD_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1
+    o = out[0]
+    assert o["n_gpus"] == 2 and o["scaling"] == "weak" and o["dry_run"] is True
+    per_rank = o["config"]["pixels_per_step_per_rank"]
+    assert len(per_rank) == 2 and all(p > 0 for p in per_rank)
+    assert per_rank[0] == o["config"]["pixels_per_step_per_gpu"]
+    assert o["config"]["batch_per_gpu"] in (47, 48, 49)         # 96 images over 2 ranks, balanced by cost
+    assert o["ms_per_step"] == pytest.approx(2000.0)             # max over ranks of the dry run's 1 s + rank
+
+
+def test_bench_refuses_gpus_that_contradict_the_launcher():
+    r, out = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+                    {"JD_BENCH_DRYRUN": "1", "WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0",
+                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}, timeout=60)
+    assert r.returncode != 0 and not out
+    assert "WORLD_SIZE=4" in r.stderr
+
+
+def test_bench_reports_a_failed_rank():
+    """a rank that dies takes the run's exit status with it, and the launcher ends the surviving rank
+    (which would otherwise sit in the rendezvous until its time-out)"""
+    import time
+    t0 = time.time()
+    r, out = _bench(["--gpus", "2", "--workload", "c5", "--batch", "48", "--distinct", "12", "--steps", "1", "--warmup", "0"],
+                    {"JD_BENCH_DRYRUN": "1", "JD_BENCH_FAIL_RANK": "1"}, timeout=200)
+    assert r.returncode != 0 and not out
+    assert "ranks failed" in r.stderr
+    assert time.time() - t0 < 120

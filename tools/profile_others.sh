@@ -7,6 +7,7 @@ for w in c2 c4 c5; do
   find gpurun_out/prof_$w -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${w}_kernel_stats.csv
   grep '^{"metric"' gpurun_out/prof_$w.log > gpurun_out/${w}_bench_line.json
 done
-JD_BENCH_REHEARSAL=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload c5 --steps 5 --warmup 2 > gpurun_out/c5_rehearsal_2ranks.log 2>&1 || exit 1
+# bench.py starts its own two ranks (no launcher): the command line the driver uses, with N = 2
+JD_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 2 --workload c5 --steps 5 --warmup 2 > gpurun_out/c5_rehearsal_2ranks.log 2>&1 || exit 1
 grep '^{"metric"' gpurun_out/c5_rehearsal_2ranks.log > gpurun_out/c5_rehearsal_2ranks.json
 cut -c1-300 gpurun_out/c5_rehearsal_2ranks.json
