@@ -1757,8 +1757,11 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
 
     const jd_pix_wg wg = wgs[wg_index()];
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
-     * the data units it never reached hold whatever the (recycled) coefficient buffer held */
-    if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL)) return;
+     * the data units it never reached hold whatever the (recycled) coefficient buffer held.  An image
+     * the write kernel left UNSYNCED (broken segment chain, overflowing narrow unit) is done again by a
+     * second pass (jdgpu_batch_sync): drawing it now would be wasted, and would stay in the buffer
+     * under a failed status if that pass then meets the real end of data */
+    if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL | JDGPU_IMG_UNSYNCED)) return;
     if (redo && redo[wg.img] == 0u) return;   /* finished by an earlier pass */
     const jd_image &im = imgs[wg.img];
     const bool nar = wide != nullptr && wide[wg.img] == 0u;   /* the image's units are in the narrow form (k_huff_write) */
@@ -2521,7 +2524,12 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
                            b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     /* chain check + repair; on a later pass (k_huff_write still found a break) the same again */
     HIPCHK(hipMemsetAsync(b->d_list_cnt, 0, (size_t)JD_REPAIR_ROUNDS * P.n * 4, st));
-    for (uint32_t r = 0; r < JD_REPAIR_ROUNDS; ++r) {
+    /* JDGPU_TEST_REPAIR_ROUNDS (tests): fewer built-in rounds in the first pass, so that chains are still
+     * broken when k_huff_write checks them and the second-pass machinery of jdgpu_batch_sync has work */
+    uint32_t rounds = JD_REPAIR_ROUNDS;
+    if (first_pass)
+        if (const char *e = getenv("JDGPU_TEST_REPAIR_ROUNDS")) rounds = min(rounds, (uint32_t)strtoul(e, nullptr, 10));
+    for (uint32_t r = 0; r < rounds; ++r) {
         uint32_t *lc = b->d_list_cnt + (size_t)r * P.n;
         hipLaunchKernelGGL(k_chain_check, grid, block, 0, st, b->d_img, b->d_seg_info, b->d_hwg, b->d_st_in, b->d_st_exit,
                            b->d_list, lc, r ? lc - P.n : (const uint32_t *)nullptr);

@@ -1142,6 +1142,60 @@ def test_failed_images_have_zero_pixels(pkg, dec, oracle):
         b.close()
 
 
+def test_failed_images_stay_zero_when_the_batch_needs_a_second_pass(pkg, dec, oracle):
+    """an image whose segment chain is still broken after the built-in repair rounds used to
+    be rendered in the first pass (status: UNSYNCED only) from coefficients decoded from wrong start
+    states; when the second pass then found the real end of data / missing code, the pixel kernel
+    returned early and the first pass's garbage stayed under a failed status.  Slowly synchronising
+    streams (white noise, quality 100, 4:4:4), damaged or cut in their later part, in one batch that
+    does need extra passes: every image that failed holds zeros, every other one equals the oracle."""
+    rng = np.random.default_rng(77)
+    files, kinds = [], []
+    for k in range(40):
+        rgb = rng.integers(0, 256, (192 + 8 * (k % 5), 256, 3), dtype=np.uint8)
+        f = bytearray(pkg.synth.encode_rgb(rgb, quality=100, subsamp=0))
+        off = oracle.parse(bytes(f))[1].scan_offset
+        n = len(f) - off
+        kind = k % 4
+        if kind == 1:                                   # cut somewhere in the last three quarters
+            f = f[:off + int(n * rng.uniform(0.25, 0.95))]
+        elif kind == 2:                                 # a burst of damaged bytes
+            at = off + int(n * rng.uniform(0.3, 0.9))
+            f[at:at + 6] = bytes(int(x) for x in rng.integers(0, 255, 6))
+        elif kind == 3:                                 # single bit flips
+            for _ in range(3):
+                f[off + int(n * rng.uniform(0.2, 0.95))] ^= 1 << int(rng.integers(0, 8))
+        files.append(bytes(f))
+        kinds.append(kind)
+    a = dec.decode([files[0]] * len(files))            # fills the buffers the next batch inherits
+    a.close()
+    # no built-in repair rounds: whatever the first guesses got wrong is still wrong when the write
+    # kernel checks the chain, the last segment's lane included -- it then reports the broken chain, not
+    # the end of data, and only the second pass (after the host's repair rounds) finds that
+    os.environ["JDGPU_TEST_REPAIR_ROUNDS"] = "0"
+    try:
+        out = dec.decode(files)
+    finally:
+        del os.environ["JDGPU_TEST_REPAIR_ROUNDS"]
+    assert out.retries >= 1                             # else this batch does not walk the path in question
+    failed = 0
+    for i, f in enumerate(files):
+        st = out.status(i)
+        rc, info, q = oracle.qcoef(f)
+        if rc:
+            want = {-2: pkg.IMG_EOF, -3: pkg.IMG_NOSYMBOL}[rc]
+            assert st & want, (i, kinds[i], rc, st)
+        if st & (pkg.IMG_EOF | pkg.IMG_NOSYMBOL):
+            failed += 1
+            assert rc != 0, (i, kinds[i], st)
+            assert not out.pixels(i).any(), (i, kinds[i], st)
+        else:
+            assert st == 0 and rc == 0, (i, st, rc)
+            assert np.array_equal(out.qcoef(i).astype(np.int32), q), i
+            assert np.array_equal(out.pixels(i), oracle.to_rgb(oracle.pixels_from_qcoef(info, q))), i
+    assert failed >= 8
+
+
 def test_one_process_one_device(pkg, dec):
     """jdgpu_init: idempotent for the bound device, refuses another one (process-wide buffer cache,
     staging buffer and constants belong to the first) -- checked before the range check, so the
