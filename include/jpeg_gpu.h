@@ -137,7 +137,12 @@ long jdgpu_parse_files(const uint8_t *const *files, const size_t *lens, size_t n
  * kernel: a DHT that assigns more codes than its lengths can hold (the reference's tree builder
  * wraps and overwrites, src/hufftree.c:46-59; no encoder writes such a table) -- that file is
  * copied back and goes through jdgpu_parse_file, so the result is the same.  Returns the number
- * of rejected files or a negative JDGPU_ERR_*. */
+ * of rejected files or a negative JDGPU_ERR_*.
+ * Padding: the scan gather of jdgpu_batch_create(JDGPU_SCAN_ON_DEVICE) reads whole aligned 32-bit
+ * words, i.e. up to 3 bytes beyond the end of a scan (never beyond the 4-byte boundary that follows
+ * it): d_files must be readable up to the next multiple of 4 after offsets[n].  Any hipMalloc'd
+ * buffer is (allocations are whole 4 KiB pages); a sub-allocator that places the files at the very
+ * end of a mapping must round its size up to 4. */
 long jdgpu_parse_files_device(const uint8_t *d_files, const uint64_t *offsets, size_t n,
                               jdgpu_image_desc *descs, int *status);
 
@@ -227,6 +232,9 @@ int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height);
  * the library (concurrent callers wait, they do not race); the array keeps the previous call's
  * bytes, which never matter -- a call reads only what it has just uploaded. */
 int jdgpu_ycbcr_to_rgb_noalloc(void *host_pixels, unsigned width, unsigned height);
+/* the limit above, in bytes (no reference counterpart either): image_ycbcr_to_rgb of include/image.h
+ * (src/image.c:39-51) stages through the static array whenever width * height * 3 fits */
+size_t jdgpu_noalloc_max_bytes(void);
 /* src/image.c:54-66 the same way (row f4 of SURVEY 8; off the decode path: image_rgb_to_ycbcr of
  * include/image.h stays host C, this is for callers whose pixels are large) */
 int jdgpu_rgb_to_ycbcr(void *host_pixels, unsigned width, unsigned height);

@@ -30,7 +30,7 @@ EXPORTS = [
     "jdgpu_batch_size", "jdgpu_batch_status", "jdgpu_batch_total_pixels",
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_pixel_pitch", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
-    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_rgb_to_ycbcr", "jdgpu_image_format",
+    "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_noalloc_max_bytes", "jdgpu_rgb_to_ycbcr", "jdgpu_image_format",
     "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
@@ -118,6 +118,7 @@ def lib():
     L.jdgpu_batch_repair_counts.argtypes = [vp, C.POINTER(C.c_uint32), sz]
     L.jdgpu_ycbcr_to_rgb.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_ycbcr_to_rgb_noalloc.argtypes = [vp, C.c_uint, C.c_uint]
+    L.jdgpu_noalloc_max_bytes.restype = sz
     L.jdgpu_rgb_to_ycbcr.argtypes = [vp, C.c_uint, C.c_uint]
     L.jdgpu_segment_bytes.restype = C.c_uint
     L.jdgpu_image_format.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, sz, C.POINTER(sz)]
@@ -322,7 +323,10 @@ class Batch:
     def segments(self, i):
         """(clean stream bytes, per-segment words) the unstuff stage produced for image i"""
         sb = self._L.jdgpu_segment_bytes()
-        cap = self.descs[i].scan_len // sb + 70000
+        # capacity: the scan's segments plus one per restart interval (at most 65535 + 1 MCU rows x columns
+        # is not known here: a batch made from files keeps no descriptors, so size by the whole batch's scans)
+        scan_len = self.descs[i].scan_len if self.descs is not None else self.total_scan_bytes
+        cap = scan_len // sb + 70000
         clean = np.empty(cap * sb, np.uint8)
         seg = np.empty(cap, np.uint32)
         n = self._L.jdgpu_batch_debug_segments(self._h, i, clean.ctypes.data, clean.size, seg.ctypes.data, seg.size)

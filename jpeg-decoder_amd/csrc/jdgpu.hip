@@ -685,9 +685,6 @@ struct BitReader {
         w1 = s == 2u ? a : w1;                     /* two shifts left w1 = w2 = the old w2 */
         w2 = s == 2u ? b : (s == 1u ? a : w2);
         c += s;
-#ifdef JD_ABL_L1LOAD   /* ablation: the loads stay, but always hit the same line */
-        qa = word(c & 3u); qb = word((c + 1u) & 3u);
-#elif !defined(JD_EAGER_LOADS)
         /* Only the lanes whose window moved load, and only the words they lack: an iteration consumes
          * a dozen bits on average, and the per-CU vector memory path (TA / L1) is what k_huff_write
          * runs into -- reloading both words in every iteration made 7 L2 read requests per load
@@ -697,9 +694,6 @@ struct BitReader {
         qa = s == 1u ? qb : qa;
         if (s == 2u) qa = *reinterpret_cast<const uint32_t *>(base + oa);
         if (s != 0u) qb = *reinterpret_cast<const uint32_t *>(base + ob);
-#else
-        qa = word(c); qb = word(c + 1u);
-#endif
         s = 0;
     }
 };
@@ -729,14 +723,7 @@ struct LightResult { uint32_t exit_state; int n, dc0, dc1, dc2; };
 #define JD_CP_BITS  (JD_SEG_BITS / (JD_CP + 1u))
 #define JD_CP_NONE  0xFFFFFFFFu
 /* bit position of checkpoint c (c == JD_CP: the end of the segment) */
-__device__ __forceinline__ constexpr uint32_t cp_mark(uint32_t c) {
-#ifdef JD_CP_MARKS
-    constexpr uint32_t m[JD_CP + 1u] = {JD_CP_MARKS, JD_SEG_BITS};
-    return m[c];
-#else
-    return (c + 1u) * JD_CP_BITS;
-#endif
-}
+__device__ __forceinline__ constexpr uint32_t cp_mark(uint32_t c) { return (c + 1u) * JD_CP_BITS; }
 
 /*
  * Light decode (no coefficient output): from packed start state `in` run to the end of the
@@ -906,16 +893,10 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
 
 /* the (image, first segment) descriptor of this wave, in scalar registers: everything derived
  * from it (image record, stream base) is then read and computed once per wave, not per lane */
-/* Work-groups go to the 8 XCDs round robin (blockIdx.x % 8).  JD_XCD_SWIZZLE (experiment, off): give every
- * XCD a contiguous eighth of the work list instead, so that its L2 sees one address range */
-__device__ __forceinline__ uint32_t wg_index() {
-#ifdef JD_XCD_SWIZZLE
-    const uint32_t per = gridDim.x >> 3, b = blockIdx.x;
-    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
-#else
-    return blockIdx.x;
-#endif
-}
+/* Work-groups go to the 8 XCDs round robin (blockIdx.x % 8) and no kernel here shares data between
+ * work-groups; giving every XCD a contiguous eighth of the work list instead was measured and lost
+ * ("Work-group order and the 8 XCDs") */
+__device__ __forceinline__ uint32_t wg_index() { return blockIdx.x; }
 __device__ __forceinline__ jd_huff_wg wave_desc(const jd_huff_wg *__restrict__ wgs, uint32_t waves) {
     const jd_huff_wg w = wgs[wg_index() * waves + (threadIdx.x >> 6)];
     jd_huff_wg u;
@@ -1380,10 +1361,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
         tb = s_blk[b]; /* once per iteration, all lanes: no divergent merge copies the descriptor around */
         R.refill(); /* all lanes, outside the divergent steps */
         /* ---- flush the units completed in this iteration (wave-synchronous) ---- */
-        uint64_t fm = __ballot(finished);
-#ifdef JD_ABL_NOFLUSH
-        fm = 0;
-#endif
+        const uint64_t fm = __ballot(finished);
         if (fm) {
             if (finished) {
                 uint32_t r = __popcll(fm & ((1ull << wlane) - 1ull));
@@ -1411,9 +1389,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                     const uint32_t top = (((uint32_t)dc << 16) & 0x0F000000u) | ((n8.y << 4) & 0xF0000000u);
                     n8.y = (n8.y & ~topmask) | (top & topmask);
                     uint32_t *out = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cbase) + (size_t)blk * JD_NARROW_UNIT) + osub;
-#ifdef JD_ABL_NOSTORE   /* ablation: the stores go to one small region */
-                    out = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cbase) + (size_t)(blk & 1023u) * JD_NARROW_UNIT) + osub;
-#endif
                     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
                     __builtin_nontemporal_store((u2){n8.x, n8.y}, reinterpret_cast<u2 *>(out));
                 } else {
@@ -1422,9 +1397,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                     *lp = make_uint4(0, 0, 0, 0);
                     /* streamed: nothing on this CU reads the unit again (6.18 -> 6.03 ms per 2048 images) */
                     uint32_t *out = reinterpret_cast<uint32_t *>(cbase + (size_t)blk * 64) + osub;
-#ifdef JD_ABL_NOSTORE
-                    out = reinterpret_cast<uint32_t *>(cbase + (size_t)(blk & 1023u) * 64) + osub;
-#endif
                     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store((u4){v.x, v.y, v.z, v.w}, reinterpret_cast<u4 *>(out));
                 }
@@ -1463,14 +1435,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
  * the reference's final "sum / 4" (src/decoding.c:83) is taken by the rounding add (to_int128) --
  * one set of constants in scalar registers, which ended the kernel's scalar register spills
  * (10.4 -> 10.0 ms). */
-/* pix_real: the arithmetic type of the IDCT.  double is the product (byte-identical to the reference on
- * every fixture); JD_ABL_PIX_F32 builds the all-float variant for the round-2 measurement of what
- * f32 would buy, never shipped. */
-#ifdef JD_ABL_PIX_F32
-typedef float pix_real;
-#else
+/* pix_real: the arithmetic type of the IDCT: double, byte-identical to the reference on every fixture
+ * (an all-float build was measured in round 2: -3.9 % of the stage, 7e-6 of the samples off by one, some
+ * pixels by two: DESIGN.md section 4) */
 typedef double pix_real;
-#endif
 template <int QUARTER>
 __device__ __forceinline__ void idct8(const pix_real in[8], pix_real out[8]) {
     constexpr pix_real S = QUARTER ? 0.25 : 1.0;
@@ -1512,15 +1480,11 @@ __device__ __forceinline__ void idct8_low(const pix_real in[4], pix_real out[8])
  * except on exact ties -- and a sum of products with the six-decimal table is never an exact
  * half-integer.  One f64 add, no conversion instruction; the clamp is done on pairs (below). */
 __device__ __forceinline__ int to_int128(pix_real v) {
-#ifdef JD_ABL_PIX_F32
-    return __float2int_rn(v * 0.25f) + 128;
-#else
     /* v is FOUR times the sample (the reference's "sum / 4", src/decoding.c:83, is left to this
      * add: with 1.5 * 2^54 the unit in the last place is 4, so the mantissa's low word is
      * RN(v / 4) + 128 -- the same bits as scaling the second pass's constants by 1/4, a power of
      * two, and one set of seven constants in scalar registers instead of two) */
     return __double2loint(v + (27021597764222976.0 + 512.0));
-#endif
 }
 __device__ __forceinline__ uint32_t cvt_pk_i16(int lo, int hi) {          /* v_cvt_pk_i16_i32: both saturated to 16 bits */
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
@@ -1688,12 +1652,7 @@ __device__ __forceinline__ void store_px4(uint8_t *rows, size_t plane, uint32_t 
         uint8_t *dst = rows + at * 3u;
         if (aligned) {
             uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-#ifdef JD_PIX_NT   /* experiment: streaming stores for the output */
-            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-            __builtin_nontemporal_store((u3){w[0], w[1], w[2]}, reinterpret_cast<u3 *>(d32));
-#else
-            d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];
-#endif
+            d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];   /* streaming (nontemporal) stores: measured, no change */
         } else {
             for (uint32_t i = 0; i < npx * 3; ++i) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
@@ -1750,10 +1709,6 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
     __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
     __shared__ uint2 s_ctab[OUT_YCBCR ? 1 : 512]; /* colour transform terms per Cb / Cr value (ctab_entry) */
-#ifdef JD_PIX_LDS_PAD   /* occupancy experiment: extra LDS per work-group */
-    __shared__ uint32_t s_pad[JD_PIX_LDS_PAD / 4];
-    if (threadIdx.x == 0 && pix_rows == 0xFFFFFFFFu) s_pad[blockIdx.x % (JD_PIX_LDS_PAD / 4)] = 1;
-#endif
 
     const jd_pix_wg wg = wgs[wg_index()];
     /* an image whose entropy decode failed keeps the zeros its output was cleared to at creation:
@@ -2778,6 +2733,8 @@ extern "C" int jdgpu_ycbcr_to_rgb_noalloc(void *host_pixels, unsigned width, uns
     HIPCHK(hipMemcpy(host_pixels, d, npix * 3, hipMemcpyDeviceToHost));
     return JDGPU_OK;
 }
+
+extern "C" size_t jdgpu_noalloc_max_bytes(void) { return JD_SCRATCH_BYTES; }
 
 extern "C" int jdgpu_ycbcr_to_rgb(void *host_pixels, unsigned width, unsigned height) {
     return convert_host_pixels(k_ycbcr_to_rgb, "jdgpu_ycbcr_to_rgb", host_pixels, width, height);

@@ -341,7 +341,12 @@ void jpeg_read_image(pixel *img, const jpeg_info *info, const scan_info *scanInf
 }
 
 void image_ycbcr_to_rgb(pixel *img, unsigned width, unsigned height) {
-    if (jdgpu_ycbcr_to_rgb(img, width, height)) die(jdgpu_last_error());
+    /* images that fit the library's static device scratch (anything up to 4096 x 2730) are staged there:
+     * no hipMalloc / hipFree per call (0.16 ms of birb.jpg's 1.36 ms); larger ones take the allocating path */
+    const size_t bytes = (size_t)width * height * 3;
+    const int rc = bytes <= jdgpu_noalloc_max_bytes() ? jdgpu_ycbcr_to_rgb_noalloc(img, width, height)
+                                                      : jdgpu_ycbcr_to_rgb(img, width, height);
+    if (rc) die(jdgpu_last_error());
 }
 
 /* ---- image.h functions that are off the decode path (host C) -------------------------------------- */

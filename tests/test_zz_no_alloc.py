@@ -1,5 +1,11 @@
 """GPU (-m gpu), collected last: jdgpu_ycbcr_to_rgb_noalloc -- the one entry point that allocates
-nothing (static device scratch) -- against jdgpu_ycbcr_to_rgb, through the C ABI."""
+nothing (static device scratch) -- against jdgpu_ycbcr_to_rgb, through the C ABI.
+
+This compares two HIP entry points with each other.  What pins the one it compares against:
+tests/test_gpu_parity.py::test_exhaustive_colour runs jdgpu_ycbcr_to_rgb (the allocating entry point, same
+kernel) over all 2^24 (Y, Cb, Cr) triples against the oracle, which tests/test_oracle_golden.py pins to the
+unmodified reference over the same 2^24 inputs.  jdgpu_ycbcr_to_rgb keeps its own hipMalloc'd staging
+buffer on purpose, so that this comparison stays one between two different staging paths."""
 import ctypes as C
 
 import numpy as np
@@ -27,6 +33,20 @@ def test_noalloc_colour_conversion_equals_the_allocating_entry_point():
         got = img.copy()
         assert L.jdgpu_ycbcr_to_rgb_noalloc(got.ctypes.data, w, h) == 0, L.jdgpu_last_error()
         assert np.array_equal(got, want), (w, h)          # integer work: bit-exact
+    # the property the entry point exists for: no device allocation.  Free device memory (hipMemGetInfo,
+    # through torch, which shares the process's HIP runtime) does not move across warm calls (the library's
+    # buffer cache is emptied first, so nothing it hands back hides an allocation)
+    import torch
+    pkg.trim()
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    assert L.jdgpu_ycbcr_to_rgb_noalloc(img.ctypes.data, 1920, 1080) == 0
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for (w, h) in ((1920, 1080), (640, 480), (4096, 2730)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert L.jdgpu_ycbcr_to_rgb_noalloc(img.ctypes.data, w, h) == 0
+        assert torch.cuda.mem_get_info()[0] == free0, (w, h)
+    assert L.jdgpu_noalloc_max_bytes() == 32 << 20
     assert 4096 * 2730 * 3 <= 32 << 20 < 4096 * 2731 * 3
     big = np.zeros((2731, 4096, 3), np.uint8)
     keep = big.copy()
