@@ -60,7 +60,12 @@ enum {
     JDGPU_IMG_EOF = 1,        /* "Reached end of file."                    src/bitstream.c:17 */
     JDGPU_IMG_NOSYMBOL = 2,   /* "Could not find next symbol in huffnode." src/hufftree.c:69,72 */
     JDGPU_IMG_UNSUPPORTED = 4,
-    JDGPU_IMG_UNSYNCED = 8    /* internal: segment chain not yet consistent (retried by decode) */
+    JDGPU_IMG_UNSYNCED = 8,   /* internal: segment chain not yet consistent (retried by decode) */
+    /* a DC value left the 16 bits the coefficient buffer holds.  The reference accumulates the
+     * predictor in an int and goes on (src/decoding.c:44-46); no stream of 8-bit samples gets there
+     * (|DC| <= 1024 * 8 / Q), so this backend reports the image instead of wrapping the value:
+     * pixels all zero, like the two failures above. */
+    JDGPU_IMG_RANGE = 16
 };
 
 /* flags for jdgpu_batch_create */
@@ -167,7 +172,7 @@ int  jdgpu_batch_create_from_files(const uint8_t *const *files, const size_t *le
 int  jdgpu_batch_decode(jdgpu_batch *b);
 /* Wait for the stream; returns JDGPU_OK or the first failure (per-image detail: _status).
  * An image whose status has JDGPU_IMG_EOF or JDGPU_IMG_NOSYMBOL (the reference exits there,
- * src/macros.h:8) has all-zero pixels; its coefficients are undefined. */
+ * src/macros.h:8) or JDGPU_IMG_RANGE has all-zero pixels; its coefficients are undefined. */
 int  jdgpu_batch_sync(jdgpu_batch *b);
 void jdgpu_batch_destroy(jdgpu_batch *b);
 

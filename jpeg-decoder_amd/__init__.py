@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("JPEGAMD_LIB") or os.path.join(_HERE, "libjpegamd.so")
 OK = 0
 ERR_HEADER = -1
 ERR_NO_DEVICE = -10
-IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED = 1, 2, 4, 8
+IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED, IMG_RANGE = 1, 2, 4, 8, 16
 OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR, OUT_PITCHED, SCAN_ON_DEVICE = 0, 1, 2, 8, 16, 32, 64
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
 

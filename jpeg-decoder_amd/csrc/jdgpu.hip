@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     BlkDesc tb = s_blk[b];
     bool own = (k == 0); /* does this lane own the data unit it is in? */
     int dcv = 0;         /* NARROW: DC value of the unit in progress */
-    uint32_t ovf = 0;    /* NARROW: an AC value that does not fit (cannot happen when `wide` is complete) */
+    uint32_t ovf = 0;    /* NARROW: an AC value that does not fit (cannot happen when `wide` is complete); wide: a DC value beyond int16 */
     uint32_t ovf2 = 0;   /* NARROW: a DC value beyond 12 bits or a last AC coefficient beyond 4, seen by a flush lane */
     int16_t *const cbase = coef + (size_t)im.blk_off * 64;
     const uint32_t bkey = NARROW ? nbuf_key(lane) : wbuf_key(lane);
@@ -1344,6 +1344,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                         *reinterpret_cast<int8_t *>(s_buf + (s_cm[kk] ^ bkey)) = (int8_t)val;
                     }
                 } else {
+                    /* a DC value that leaves int16 (the reference keeps it in an int, src/decoding.c:44-46; no
+                     * stream of 8-bit samples gets there): reported, not wrapped -- JDGPU_IMG_RANGE below.  AC
+                     * values have at most 15 magnitude bits and always fit */
+                    ovf |= (isdc && ok) ? (uint32_t)(val + 32768) : 0u;
                     if (ok && (isdc || (own && size != 0u && kk < 64u)))
                         *reinterpret_cast<int16_t *>(s_buf + ((2u * s_cm[kk & 63u]) ^ bkey)) = (int16_t)val;
                 }
@@ -1413,6 +1417,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
         atomicOr(&wide[wg.img], 1u);
         flags |= JDGPU_IMG_UNSYNCED;
     }
+    if (!NARROW && (ovf & ~65535u)) flags |= JDGPU_IMG_RANGE;
     if (flags) atomicOr(&status[wg.img], flags);
 }
 
@@ -1716,7 +1721,7 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
      * the write kernel left UNSYNCED (broken segment chain, overflowing narrow unit) is done again by a
      * second pass (jdgpu_batch_sync): drawing it now would be wasted, and would stay in the buffer
      * under a failed status if that pass then meets the real end of data */
-    if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL | JDGPU_IMG_UNSYNCED)) return;
+    if (status[wg.img] & (uint32_t)(JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL | JDGPU_IMG_UNSYNCED | JDGPU_IMG_RANGE)) return;
     if (redo && redo[wg.img] == 0u) return;   /* finished by an earlier pass */
     const jd_image &im = imgs[wg.img];
     const bool nar = wide != nullptr && wide[wg.img] == 0u;   /* the image's units are in the narrow form (k_huff_write) */

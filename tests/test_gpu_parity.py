@@ -832,6 +832,76 @@ def test_narrow_units_and_what_does_not_fit_them(pkg, dec, oracle):
     assert out.retries == 0
 
 
+def test_dc_values_beyond_16_bits_are_reported_not_wrapped(pkg, dec, oracle):
+    """VERDICT r2 #7a.  The reference keeps the DC predictor in an int (src/decoding.c:44-46); the
+    coefficient buffer here holds int16.  Flat units whose DC climbs by the largest difference the
+    Annex K table codes (11 bits): up to +-32767 the values come out as the oracle's; one step
+    further the image is reported (JDGPU_IMG_RANGE, pixels zero) instead of wrapping silently, on
+    the narrow-then-wide path a small batch takes and with the wide kernel from the start; its
+    neighbours in the batch are untouched."""
+    up = [(128 + 255 * k, 128, 128 - 255 * k) for k in range(17)]           # DC 0, 2040, ... 32640 / 0 ... -32640
+    fits = _flat_block_jpeg(pkg, oracle, up, 8 * 17, 8, q63=16)
+    over = _flat_block_jpeg(pkg, oracle, up + [(128 + 255 * 17, 128, 128 - 255 * 17)] * 3, 8 * 20, 8, q63=16)
+    q_fit, q_over = oracle.qcoef(fits)[2], oracle.qcoef(over)[2]
+    assert q_fit[:, 0].max() == 32640 and q_fit[:, 0].min() == -32640
+    assert q_over[:, 0].max() == 34680 and q_over[:, 0].min() == -34680      # the oracle (= the reference) goes on
+    good = golden_stream("syn_64x48_420_q85")
+    for env in ({}, {"JDGPU_NARROW": "0"}):
+        if env:   # JDGPU_NARROW is read once per process: the wide-only run is a child process
+            code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                    "import numpy as np, __graft_entry__ as ge\n"
+                    "from test_gpu_parity import _flat_block_jpeg\n"
+                    "from oracle.oracle import Oracle\n"
+                    "pkg = ge.load_package(); o = Oracle(); dec = pkg.Decoder(0)\n"
+                    "up = [(128 + 255 * k, 128, 128 - 255 * k) for k in range(17)]\n"
+                    "fits = _flat_block_jpeg(pkg, o, up, 8 * 17, 8, q63=16)\n"
+                    "over = _flat_block_jpeg(pkg, o, up + [(128 + 255 * 17, 128, 128 - 255 * 17)] * 3, 8 * 20, 8, q63=16)\n"
+                    "out = dec.decode([fits, over])\n"
+                    "assert out.status(0) == 0 and np.array_equal(out.qcoef(0).astype(np.int32), o.qcoef(fits)[2])\n"
+                    "assert out.status(1) == pkg.IMG_RANGE and not out.pixels(1).any()\n"
+                    "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+            r = subprocess.run([os.sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+            continue
+        out = dec.decode([good, fits, over, good])
+        _check_against_oracle(pkg, oracle, out, 0, good)
+        _check_against_oracle(pkg, oracle, out, 1, fits)
+        _check_against_oracle(pkg, oracle, out, 3, good)
+        assert out.status(2) == pkg.IMG_RANGE, out.status(2)
+        assert not out.pixels(2).any()
+
+
+def test_dc_symbols_of_16_and_more_are_no_symbol(pkg, dec, oracle):
+    """VERDICT r2 #7b, a documented departure pinned here.  A DC Huffman symbol is a magnitude size; the
+    reference reads `symbol` bits whatever it is, up to 32 (src/decoding.c:43-44, src/bitstream.c:38).  T.81
+    allows 0..11 for 8-bit samples; this backend's tables hold sizes 0..15 and treat a larger DC symbol
+    as a code that does not exist: JDGPU_IMG_NOSYMBOL, pixels zero.  The oracle follows the reference (it
+    reads the 17 bits and decodes on): the two differ on such a stream, on purpose."""
+    base = golden_stream("syn_64x48_444_q85")
+    b = bytearray(base)
+    at = base.index(b"\xff\xc4")
+    assert b[at + 4] == 0x00                             # DC table 0
+    nsym = sum(b[at + 5:at + 21])
+    syms = b[at + 21:at + 21 + nsym]
+    k = list(syms).index(0)                              # the "no difference" category, used by flat areas
+    b[at + 21 + k] = 17
+    data = bytes(b)
+    rc, _info, _q = oracle.qcoef(data)
+    assert rc in (0, -2, -3)                             # reads 17 bits and carries on, wherever that leads
+    out = dec.decode([base, data, base])
+    assert out.status(1) & pkg.IMG_NOSYMBOL and not out.pixels(1).any()
+    _check_against_oracle(pkg, oracle, out, 0, base)
+    _check_against_oracle(pkg, oracle, out, 2, base)
+    # a table that merely LISTS such a symbol and never uses it decodes as if it were not there
+    b = bytearray(base)
+    b[at + 21 + list(syms).index(11)] = 200              # category 11: differences of 1024 and more, absent from this image
+    listed = bytes(b)
+    rc, _info, q = oracle.qcoef(listed)
+    assert rc == 0 and np.array_equal(q, oracle.qcoef(base)[2])
+    out = dec.decode([listed])
+    _check_against_oracle(pkg, oracle, out, 0, listed)
+
+
 def test_missing_restart_markers_are_eof(pkg, dec, oracle):
     """streams whose restart markers were destroyed (found by tools/soak.py): the trailing restart
     intervals never start, their data units are missing -> "Reached end of file." like the
