@@ -735,7 +735,7 @@ template <bool COMPARE>
 __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables &T, uint32_t in, uint32_t valid,
                                                     uint32_t *__restrict__ cp_state, int4 *__restrict__ cp_val,
                                                     uint32_t old_exit) {
-    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
+    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = JD_ST_UNIT(in);
     uint32_t fl = 0;             /* OR of the entries since the last checkpoint: LE_WIDE, LE_BAD */
     int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;  /* units completed, DC difference sums since the last checkpoint */
     int tn = 0, t0 = 0, t1 = 0, t2 = 0;    /* ... up to the last checkpoint */
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     const int limit = sb.y;
     int pr0 = sd.x, pr1 = sd.y, pr2 = sd.z;
 
-    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = (in >> 13) & 15u;
+    uint32_t p = in & 63u, k = (in >> 6) & 127u, b = JD_ST_UNIT(in);
     uint32_t vend = valid;      /* units that start before this bit are the lane's */
     bool last_sub = true;       /* the lane that reaches the end of the segment's data */
     if (SUB > 1u) {
@@ -1711,8 +1711,10 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     constexpr uint32_t TILE_BYTES = PLANE2 + (FAST ? (GRAY ? 0u : 8u * PIX_ROW) : PLANE_BYTES);
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[JD_PIX_WAVES][TILE_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_q[4][64];
-    __shared__ uint32_t s_meta[16]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
-    __shared__ uint16_t s_jmap[8 * JD_MAX_BPM]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
+    constexpr uint32_t MAXB = FAST ? 6u : JD_MAX_BPM;      /* data units per MCU: the layouts with an instantiation have at most 2x2 + 1 + 1 */
+    constexpr uint32_t NJMAP = FAST ? 8u * MAXB : JD_JMAP;
+    __shared__ uint32_t s_meta[MAXB]; /* per data unit of the MCU: comp | tq << 2 | h << 4 | v << 6 | H << 8 (4 bits) | plane offset / 64 << 12 */
+    __shared__ uint16_t s_jmap[NJMAP]; /* j-th data unit of a wave's part of the strip: MCU | unit << 8 */
     __shared__ uint2 s_ctab[OUT_YCBCR ? 1 : 512]; /* colour transform terms per Cb / Cr value (ctab_entry) */
 
     const jd_pix_wg wg = wgs[wg_index()];
@@ -1734,13 +1736,13 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
     const uint32_t bpm = FAST ? (GRAY ? 1u : (1u << (HSH + VSH)) + 2u) : im.bpm;
     const uint32_t sub_mcus = SUB_PX / (8u * maxH);
     for (uint32_t i = tid; i < 256; i += 64 * JD_PIX_WAVES) s_q[i >> 6][i & 63u] = im.quant[i >> 6][i & 63u];
-    if (tid < JD_MAX_BPM) {
+    if (tid < MAXB) {
         uint32_t c = im.blk_comp[tid];
         const uint32_t plane = c == 0 ? 0u : c == 1 ? PLANE1 : PLANE2;   /* multiples of 64 bytes */
         s_meta[tid] = c | ((uint32_t)im.comp_tq[c] << 2) | ((uint32_t)im.blk_h[tid] << 4) | ((uint32_t)im.blk_v[tid] << 6) |
                       ((uint32_t)im.comp_H[c] << 8) | ((plane >> 6) << 12);
     }
-    if (tid < 8 * JD_MAX_BPM) {
+    if (tid < NJMAP) {
         /* order in which a wave takes the data units of its part of an MCU row, 8 at a time.  Generic:
          * as stored.  The layouts with an instantiation: all luma units first, then Cb, then Cr, so that
          * a group of 8 is of one kind -- chroma units seldom hold a coefficient beyond the low 4 x 4,
@@ -1982,22 +1984,26 @@ __global__ __launch_bounds__(64 * JD_PIX_WAVES) void k_pixel(const jd_image *__r
                     }
                 }
             } else {
-                /* any mix of 1x and 2x factors and any channel order: per-sample gathers.
-                 * replication shift per component: maxH/H, maxV/V in {1,2,4} (src/jpeg.c:82) */
+                /* any mix of factors 1..4 whose replication ratios maxH/H, maxV/V are whole numbers
+                 * (src/jpeg.c:82), and any channel order: per-sample gathers.  Pixel p of the MCU row takes
+                 * sample p / ratio: a multiply-shift, floor(p * rcp / 512) with rcp = 512, 256, 171, 128 for
+                 * ratio 1..4 (exact for p < 512; p < 64 here) */
                 uint32_t hs[3], vs[3], ch[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    hs[c] = (maxH / im.comp_H[c]) >> 1; vs[c] = (maxV / im.comp_V[c]) >> 1; ch[c] = im.comp_chan[c];
+                    hs[c] = (512u + maxH / im.comp_H[c] - 1u) / (maxH / im.comp_H[c]);
+                    vs[c] = (512u + maxV / im.comp_V[c] - 1u) / (maxV / im.comp_V[c]);
+                    ch[c] = im.comp_chan[c];
                 }
                 for (uint32_t r = rq; r < rows; r += 4) {
                     uint32_t sm[3][4]; /* sm[channel][pixel]; channel = component id - 1 (src/decoding.c:107) */
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const uint8_t *tp = &tile[c * PLANE_BYTES + (r >> vs[c]) * PIX_ROW];
+                        const uint8_t *tp = &tile[c * PLANE_BYTES + ((r * vs[c]) >> 9) * PIX_ROW];
                         const bool absent = (uint32_t)c >= im.ncomp; /* grayscale: neutral chroma */
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            uint32_t v = absent ? 128u : tp[(4u * g + i) >> hs[c]];
+                            uint32_t v = absent ? 128u : tp[((4u * g + i) * hs[c]) >> 9];
                             if (ch[c] == 0) sm[0][i] = v; else if (ch[c] == 1) sm[1][i] = v; else sm[2][i] = v;
                         }
                     }

@@ -24,7 +24,7 @@ extern "C" {
 #define JD_SEG_BYTES   (JD_SEG_WORDS * 4u)    /* 512 B  */
 #define JD_SEG_BITS    (JD_SEG_BYTES * 8u)    /* 4096 b */
 #define JD_WG_SEGS     256u                   /* segments (= lanes) per work-group, sync kernels */
-#define JD_MAX_BPM     12u                    /* data units per MCU: 3 components of at most 2x2 */
+#define JD_MAX_BPM     48u                    /* data units per MCU: 3 components of at most 4x4 (src/parsing.c:42-46) */
 #define JD_LUT_BITS    10u                    /* primary Huffman lookup width */
 #define JD_LUT_SLOTS   6u                     /* distinct tables a 3-component scan can use */
 
@@ -109,9 +109,10 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut_hot *h, const jd_lut *t, uint32_t v16) {
 
 /* decoder state at a segment boundary, packed */
 /* bits 5:0 overshoot into the next segment, 12:6 zigzag index k (0 = expecting DC),
- * 16:13 data unit within the MCU, 17 decode error seen */
+ * 18:13 data unit within the MCU (0 .. JD_MAX_BPM - 1), 19 decode error seen */
 #define JD_ST_PACK(ovs, k, b) ((uint32_t)(ovs) | ((uint32_t)(k) << 6) | ((uint32_t)(b) << 13))
-#define JD_ST_BAD 0x20000u
+#define JD_ST_UNIT(st) (((st) >> 13) & 63u)
+#define JD_ST_BAD 0x80000u
 #define JD_ST_NONE 0xFFFFFFFFu
 
 #define JD_NARROW_MIN_Q63 8u
@@ -191,6 +192,10 @@ typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK
 #define JD_PIX_WAVES 4u    /* waves per pixel-kernel work-group; each wave owns 64 pixels of the strip */
 #endif
 #define JD_STRIP_PX (64u * JD_PIX_WAVES)  /* pixel-kernel strip width */
+/* MCU columns a pixel work-group covers: every wave takes the whole MCUs that fit its 64 pixels (2 of the
+ * 24-pixel MCUs of a layout with horizontal factor 3) */
+#define JD_STRIP_MCUS(maxH) (JD_PIX_WAVES * (64u / (8u * (maxH))))
+#define JD_JMAP 96u   /* most data units a wave has per MCU row: (64 / (8 maxH)) MCUs x (<= 3 * 4 * maxH) units */
 #define JD_PIX_ROWS_MAX 16u  /* MCU rows a pixel-kernel work-group walks down at most (loads run one row ahead);
                                 the plan takes fewer when the batch is too small to fill the chip otherwise */
 #define JD_PIX_GENERIC 0u

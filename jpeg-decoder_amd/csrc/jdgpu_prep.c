@@ -185,16 +185,20 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
             unsigned id = d->comp[c].id;
             if (id < 1 || id > 3 || (seen >> id & 1)) ok = 0; /* channel = id-1, SURVEY 8(c) */
             seen |= 1u << id;
-            /* factors 1, 2 and 4 (4:1:1, 4:1:0): the replication ratios maxH/H, maxV/V are then powers
-             * of two, as the pixel kernel's shifts need; the reference takes 1..4 (src/parsing.c:42-46) */
-            if ((d->comp[c].H != 1 && d->comp[c].H != 2 && d->comp[c].H != 4) ||
-                (d->comp[c].V != 1 && d->comp[c].V != 2 && d->comp[c].V != 4)) ok = 0;
+            /* factors 1..4, as the reference takes them (src/parsing.c:42-46) */
+            if (d->comp[c].H < 1 || d->comp[c].H > 4 || d->comp[c].V < 1 || d->comp[c].V > 4) ok = 0;
             if (d->comp[c].Tq > 3 || d->comp[c].Td > 3 || d->comp[c].Ta > 3) ok = 0;
             if (ok && (!d->huff_defined[0][d->comp[c].Td] || !d->huff_defined[1][d->comp[c].Ta])) ok = 0;
             if (d->comp[c].H > maxH) maxH = d->comp[c].H;
             if (d->comp[c].V > maxV) maxV = d->comp[c].V;
         }
-        if (units > JD_MAX_BPM) ok = 0; /* 4x4 luma + chroma: 18 data units per MCU, beyond the state word's unit field */
+        if (units > JD_MAX_BPM) ok = 0; /* cannot happen: 3 components of at most 4x4 */
+        /* The replication ratios must be whole numbers.  The reference stretches by the integer quotient
+         * maxH / H (src/jpeg.c:82): with, say, luma 3x1 beside a 2x1 component that one's units cover 16 of
+         * the MCU's 24 columns and the rest of its channel is whatever malloc left (src/test.c:28) -- no
+         * output to be identical to. */
+        for (unsigned c = 0; ok && c < nc; ++c)
+            if (maxH % d->comp[c].H || maxV % d->comp[c].V) ok = 0;
         im->width = d->width; im->height = d->height;
         im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
         im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
@@ -284,7 +288,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         im->n_chunks = (uint32_t)((d->scan_len + JD_RAW_CHUNK - 1) / JD_RAW_CHUNK);
         nu += im->n_intervals + 1; nr += im->n_chunks;
         segs += im->seg_cap; ivls += im->n_intervals; blk += im->n_blocks;
-        uint32_t strip = JD_STRIP_PX / (8u * maxH);
+        uint32_t strip = JD_STRIP_MCUS(maxH);
         np += im->mcus_y * ((im->mcus_x + strip - 1) / strip); /* single-row strips: regrouped below */
     }
     P->raw_bytes = raw + 64; P->clean_bytes = clean + JD_SEG_BYTES * 2;
@@ -437,7 +441,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         for (size_t i = 0; i < n; ++i) {
             jd_image *im = &P->img[i];
             if (!im->ncomp || im->pix_mode != mode) continue;
-            uint32_t strip = JD_STRIP_PX / (8u * im->maxH);
+            uint32_t strip = JD_STRIP_MCUS(im->maxH);
             for (uint32_t r = 0; r < im->mcus_y; r += P->pix_rows)
                 for (uint32_t c = 0; c < im->mcus_x; c += strip) {
                     P->pwg[np].img = (uint32_t)i; P->pwg[np].mcu_row = (uint16_t)r; P->pwg[np].mcu_col0 = (uint16_t)c; ++np;

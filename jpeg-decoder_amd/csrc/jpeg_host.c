@@ -332,7 +332,7 @@ void jpeg_read_image(pixel *img, const jpeg_info *info, const scan_info *scanInf
     if (!rc) rc = jdgpu_batch_sync(b);
     if (rc) die(jdgpu_last_error());
     uint32_t st = jdgpu_batch_status(b, 0);
-    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components or 1, ids 1..3, sampling factors 1, 2 or 4, at most 12 data units per MCU).");
+    if (st & JDGPU_IMG_UNSUPPORTED) die("Unsupported component layout (need 3 components or 1, ids 1..3, sampling factors 1..4 that divide the largest one).");
     if (st & JDGPU_IMG_NOSYMBOL) die("Could not find next symbol in huffnode."); /* src/hufftree.c:69,72 */
     if (st & JDGPU_IMG_EOF) die("Reached end of file.");                         /* src/bitstream.c:17 */
     if (st & JDGPU_IMG_RANGE) die("A DC coefficient leaves 16 bits (the GPU backend keeps quantised coefficients in int16).");

@@ -166,7 +166,8 @@ static void scale_q(const uint8_t base[64], int quality, uint8_t out[64]) {
 /*
  * Encode interleaved RGB (w*h*3).  subsamp: 0 = 4:4:4, 1 = 4:2:0, 2 = 4:2:2 (luma 2x1),
  * 3 = 4:4:0 (luma 1x2), 4 = grayscale (one component, id 1, luma only), 5 = 4:1:1 (luma 4x1),
- * 6 = 4:1:0 (luma 4x2), 7 = luma 1x4, 8 = luma 2x4.  restart_mcus: 0 = no DRI.
+ * 6 = 4:1:0 (luma 4x2), 7 = luma 1x4, 8 = luma 2x4; 0x100 | H << 4 | V = luma H x V (1..4 each), chroma
+ * 1x1.  restart_mcus: 0 = no DRI.
  * Returns the number of bytes the stream needs; if it exceeds cap the buffer content is
  * undefined (call again with a bigger buffer).
  */
@@ -178,6 +179,8 @@ size_t jsynth_encode_rgb(const uint8_t *rgb, int w, int h, int quality, int subs
     scale_q(K_LUMA_Q, quality, ql); scale_q(K_CHROMA_Q, quality, qc);
     int ssh = (subsamp == 1 || subsamp == 2 || subsamp == 8) ? 2 : (subsamp == 5 || subsamp == 6) ? 4 : 1;
     int ssv = (subsamp == 1 || subsamp == 3 || subsamp == 6) ? 2 : (subsamp == 7 || subsamp == 8) ? 4 : 1;
+    if (subsamp & 0x100) { ssh = (subsamp >> 4) & 15; ssv = subsamp & 15; }
+    if (ssh < 1 || ssh > 4 || ssv < 1 || ssv > 4) return 0;
     int mcuw = 8 * ssh, mcuh = 8 * ssv;
     int mx = (w + mcuw - 1) / mcuw, my = (h + mcuh - 1) / mcuh;
     int pw = mx * mcuw, ph = my * mcuh;

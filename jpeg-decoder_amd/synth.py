@@ -34,7 +34,7 @@ def _lib():
 def make_jpeg(w, h, seed=1234, quality=85, subsamp=1, restart_mcus=0):
     """Deterministic test-pattern JPEG.  subsamp: 0 = 4:4:4, 1 = 4:2:0, 2 = 4:2:2,
     3 = 4:4:0, 4 = grayscale (one component), 5 = 4:1:1 (luma 4x1), 6 = 4:1:0 (luma 4x2),
-    7 = luma 1x4, 8 = luma 2x4."""
+    7 = luma 1x4, 8 = luma 2x4; 0x100 | H << 4 | V = luma H x V (factors 1..4), chroma 1x1."""
     cap = w * h * 6 + 65536   # white noise at quality 100 codes to more than the raw size
     buf = np.empty(cap, np.uint8)
     n = _lib().jsynth_make(w, h, seed, quality, subsamp, restart_mcus, buf.ctypes.data, cap)

@@ -54,6 +54,17 @@ SYNTH = [
     ("syn_48x64_v4_q85", 48, 64, 14, 85, 7, 0),
     ("syn_104x72_411_q70", 104, 72, 15, 70, 5, 0),
     ("syn_80x96_2x4_q90", 80, 96, 16, 90, 8, 0),
+    # sampling factor 3 and the largest layout, luma 4x4 (18 data units per MCU): 0x100 | H << 4 | V = luma
+    # H x V, chroma 1x1; sizes multiples of the replication, some not of the MCU
+    ("syn_72x48_3x1_q85", 72, 48, 17, 85, 0x131, 0),
+    ("syn_78x40_3x1_q80", 78, 40, 18, 80, 0x131, 0),
+    ("syn_48x72_1x3_q85", 48, 72, 19, 85, 0x113, 0),
+    ("syn_96x72_3x3_q90", 96, 72, 20, 90, 0x133, 0),
+    ("syn_120x51_3x3_q75", 120, 51, 21, 75, 0x133, 0),
+    ("syn_96x48_3x2_q85", 96, 48, 22, 85, 0x132, 0),
+    ("syn_72x64_3x4_q80", 72, 64, 23, 80, 0x134, 0),
+    ("syn_96x64_4x4_q85", 96, 64, 24, 85, 0x144, 0),
+    ("syn_104x72_4x4_q70", 104, 72, 25, 70, 0x144, 0),
 ]
 # DRI twins of non-DRI streams: (name, base name, restart_mcus)
 SYNTH_DRI = [
@@ -61,6 +72,8 @@ SYNTH_DRI = [
     ("syn_200x136_420_q50_dri13", "syn_200x136_420_q50", 13),
     ("syn_200x136_444_q95_dri1", "syn_200x136_444_q95", 1),
     ("syn_640x360_420_q85_dri40", "syn_640x360_420_q85", 40),
+    ("syn_96x72_3x3_q90_dri2", "syn_96x72_3x3_q90", 2),
+    ("syn_104x72_4x4_q70_dri3", "syn_104x72_4x4_q70", 3),
 ]
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: randomized parity soak on the GPU box.  N random streams (sizes 1..400, all five
-layouts plus the four with a sampling factor of 4, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
+layouts, the four with a sampling factor of 4 and every luma H x V of 1..4, qualities 1..100, restart intervals, white-noise and flat content, random corruptions)
 decoded in batches of 256 in every output layout (dense and pitched rows; every other batch through
 jdgpu_batch_create_from_files), each compared with the oracle: status class,
 coefficients and pixels bit for bit.  usage: soak.py [N] [seed] [max_side, default 400]"""
@@ -32,6 +32,9 @@ while done < N:
         q = int(rng.integers(1, 101))
         mw = {1: 16, 2: 16, 5: 32, 6: 32, 8: 16}.get(ss, 8)
         mh = {1: 16, 3: 16, 6: 16, 7: 32, 8: 32}.get(ss, 8)
+        if rng.random() < 0.25:   # any luma H x V of 1..4 (factor 3, 4x4 = 18 data units per MCU), chroma 1x1
+            lh, lv = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+            ss, mw, mh = 0x100 | lh << 4 | lv, 8 * lh, 8 * lv
         mcus = -(-w // mw) * -(-h // mh)
         ri = 0 if rng.random() < 0.5 else int(rng.integers(1, mcus + 2))
         kind = rng.random()
