@@ -151,6 +151,16 @@ long jdgpu_parse_files(const uint8_t *const *files, const size_t *lens, size_t n
 long jdgpu_parse_files_device(const uint8_t *d_files, const uint64_t *offsets, size_t n,
                               jdgpu_image_desc *descs, int *status);
 
+/* Pinned host memory for the files of coming batches (no counterpart in the reference, which reads one
+ * file through getc, src/bitstream.c:12-14): a loader that reads its files into such a region spares every
+ * batch creation the copy into the library's staging buffer.  jdgpu_batch_create and
+ * jdgpu_batch_create_from_files notice by themselves that all scans / files of a batch lie in one such
+ * region and upload the span that holds them in one DMA from where it lies (a batch that uses less than
+ * half of the bytes between its first and last file goes through the staging buffer as before).  The
+ * region must stay as it is until the creation call returns.  NULL when the allocation fails. */
+void *jdgpu_pinned_alloc(size_t bytes);
+void  jdgpu_pinned_free(void *p);
+
 /* ---- batched decode: replaces jpeg_read_image (src/jpeg.c:63-88) and, with JDGPU_OUT_RGB,
  *      image_ycbcr_to_rgb (src/image.c:39-51), for n independent images ---------------------- */
 
@@ -204,6 +214,12 @@ void    *jdgpu_batch_device_pixels(jdgpu_batch *b, size_t i);
 int      jdgpu_batch_read_coefficients(jdgpu_batch *b, size_t i, int16_t *dst);
 /* HIP-event milliseconds per stage of the most recent decode (needs JDGPU_PROFILE). */
 int      jdgpu_batch_stage_ms(jdgpu_batch *b, float ms[JDGPU_NSTAGES]);
+/* Where the creation of the batch spent its host time, in milliseconds: building the plan; copying scans or
+ * files into the library's pinned staging buffer (0 when they came from jdgpu_pinned_alloc memory or from the
+ * device); the uploads (scans / files, tables, work lists) and the device-side gather; everything else
+ * (allocations, header parse on the device and its read-back). */
+enum { JDGPU_CREATE_PLAN = 0, JDGPU_CREATE_STAGE = 1, JDGPU_CREATE_UPLOAD = 2, JDGPU_CREATE_OTHER = 3, JDGPU_NCREATE = 4 };
+int      jdgpu_batch_create_ms(const jdgpu_batch *b, float ms[JDGPU_NCREATE]);
 /* number of extra passes the last decode needed: 0 in the common case; each one costs a host round
  * trip, the repair rounds again and a scan/write/pixel pass over the images that were left
  * unfinished (a segment chain still broken, a coefficient beyond the 64-byte unit form) -- the

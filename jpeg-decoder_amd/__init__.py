@@ -22,6 +22,7 @@ ERR_NO_DEVICE = -10
 IMG_EOF, IMG_NOSYMBOL, IMG_UNSUPPORTED, IMG_UNSYNCED, IMG_RANGE = 1, 2, 4, 8, 16
 OUT_RGB, OUT_YCBCR, PROFILE, OUT_4BYTE, OUT_PLANAR, OUT_PITCHED, SCAN_ON_DEVICE = 0, 1, 2, 8, 16, 32, 64
 STAGES = ("unstuff", "sync", "scan", "write", "pixel", "total")
+CREATE_PARTS = ("plan", "stage", "upload", "other")
 
 EXPORTS = [
     "jdgpu_device_count", "jdgpu_init", "jdgpu_last_error", "jdgpu_trim", "jdgpu_parse_file", "jdgpu_parse_files",
@@ -31,7 +32,7 @@ EXPORTS = [
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_pixel_pitch", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_noalloc_max_bytes", "jdgpu_rgb_to_ycbcr", "jdgpu_image_format",
-    "jdgpu_batch_debug_segments", "jdgpu_segment_bytes",
+    "jdgpu_batch_debug_segments", "jdgpu_segment_bytes", "jdgpu_pinned_alloc", "jdgpu_pinned_free", "jdgpu_batch_create_ms",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
     "image_print", "image_ycbcr_to_rgb", "image_rgb_to_ycbcr",
@@ -124,6 +125,11 @@ def lib():
     L.jdgpu_image_format.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, sz, C.POINTER(sz)]
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]
     L.jdgpu_batch_debug_segments.restype = C.c_long
+    L.jdgpu_pinned_alloc.argtypes = [sz]
+    L.jdgpu_pinned_alloc.restype = vp
+    L.jdgpu_pinned_free.argtypes = [vp]
+    L.jdgpu_pinned_free.restype = None
+    L.jdgpu_batch_create_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -182,15 +188,59 @@ class DescArray:
         return (self.arr[i] for i in range(self.n))
 
 
+class Arena:
+    """Files copied back to back (16-byte aligned starts) into ONE region of pinned host memory
+    (jdgpu_pinned_alloc): what a loader that reads its files straight into pinned memory holds.  parse_many
+    and Batch.from_files take it in place of a list of byte strings; batch creation then uploads from
+    where the files lie instead of copying them into the library's staging buffer first."""
+
+    def __init__(self, files):
+        L = self._L = lib()
+        sizes = [len(f) for f in files]
+        total = sum((s + 15) & ~15 for s in sizes) + 16
+        self.ptr = L.jdgpu_pinned_alloc(total)
+        if not self.ptr:
+            raise _err(L, "jdgpu_pinned_alloc", -11)
+        self.buf = np.ctypeslib.as_array((C.c_uint8 * total).from_address(self.ptr))
+        self.views, at = [], 0
+        for f, s in zip(files, sizes):
+            self.buf[at:at + s] = np.frombuffer(f, np.uint8)
+            self.views.append(self.buf[at:at + s])
+            at += (s + 15) & ~15
+        n = len(sizes)
+        # the (pointer, length) arrays the C calls take, made once: a loader's per-batch Python work is then a few calls
+        self.ptrs = (C.c_void_p * max(1, n))(*[v.ctypes.data if v.size else None for v in self.views])
+        self.lens = (C.c_size_t * max(1, n))(*sizes)
+
+    def __len__(self):
+        return len(self.views)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.views, self.buf = [], None
+            self._L.jdgpu_pinned_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def parse_many(files, threads=0, strict=True):
     """jdgpu_parse_files: the headers of many files on `threads` host threads (0 = per core).
     strict: raise on the first rejected header, as parse() does; otherwise rejected files keep a
-    zeroed descriptor (decoded as IMG_UNSUPPORTED) and .status holds the codes."""
+    zeroed descriptor (decoded as IMG_UNSUPPORTED) and .status holds the codes.  files: byte strings, or
+    an Arena (parsed where they lie: the descriptors' scan pointers then point into pinned memory)."""
     L = lib()
     n = len(files)
-    keep = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
-    ptrs = (C.c_void_p * max(1, n))(*[k.ctypes.data if k.size else None for k in keep])
-    lens = (C.c_size_t * max(1, n))(*[k.size for k in keep])
+    if isinstance(files, Arena):
+        keep, ptrs, lens = files, files.ptrs, files.lens
+    else:
+        keep = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+        ptrs = (C.c_void_p * max(1, n))(*[k.ctypes.data if k.size else None for k in keep])
+        lens = (C.c_size_t * max(1, n))(*[k.size for k in keep])
     arr = (ImageDesc * max(1, n))()
     status = (C.c_int * max(1, n))()
     bad = L.jdgpu_parse_files(ptrs, lens, n, arr, status, threads)
@@ -226,9 +276,12 @@ class Batch:
         on the GPU.  self.file_status: per-file 0 / ERR_HEADER."""
         L = lib()
         n = len(files)
-        bufs = [np.frombuffer(f, np.uint8) for f in files]
-        ptrs = (C.c_void_p * max(1, n))(*[b.ctypes.data for b in bufs])
-        lens = (C.c_size_t * max(1, n))(*[b.size for b in bufs])
+        if isinstance(files, Arena):
+            ptrs, lens = files.ptrs, files.lens
+        else:
+            bufs = [np.frombuffer(f, np.uint8) for f in files]
+            ptrs = (C.c_void_p * max(1, n))(*[b.ctypes.data for b in bufs])
+            lens = (C.c_size_t * max(1, n))(*[b.size for b in bufs])
         status = (C.c_int * max(1, n))()
         h = C.c_void_p()
         rc = L.jdgpu_batch_create_from_files(ptrs, lens, n, flags, C.byref(h), status)
@@ -237,12 +290,21 @@ class Batch:
         self = cls.__new__(cls)
         self._L, self._h, self.flags, self.n, self.descs = L, h, flags, n, None
         self.file_status = list(status)[:n]
-        self.dims = []
-        for i in range(n):
-            w, hh = C.c_uint(), C.c_uint()
-            L.jdgpu_batch_image_size(h, i, C.byref(w), C.byref(hh))
-            self.dims.append((w.value, hh.value))
+        self._dims = None
         return self
+
+    @property
+    def dims(self):
+        """(width, height) per image; a batch made from files asks the library on first use"""
+        if self._dims is None and self.descs is not None:
+            self._dims = [(d.width, d.height) for d in self.descs]
+        if self._dims is None:
+            self._dims = []
+            for i in range(self.n):
+                w, hh = C.c_uint(), C.c_uint()
+                self._L.jdgpu_batch_image_size(self._h, i, C.byref(w), C.byref(hh))
+                self._dims.append((w.value, hh.value))
+        return self._dims
 
     def __init__(self, descs, flags=OUT_RGB):
         L = self._L = lib()
@@ -258,7 +320,8 @@ class Batch:
         self._h = h
         self.flags = flags
         self.n = len(self.descs)
-        self.dims = [(d.width, d.height) for d in self.descs]
+        self._dims = None if isinstance(descs, DescArray) else [(d.width, d.height) for d in self.descs]
+        self._arr = arr
 
     def decode(self, sync=True):
         rc = self._L.jdgpu_batch_decode(self._h)
@@ -340,6 +403,14 @@ class Batch:
         if rc:
             raise _err(self._L, "jdgpu_batch_stage_ms", rc)
         return dict(zip(STAGES, [float(x) for x in ms]))
+
+    def create_ms(self):
+        """where the creation of this batch spent its host time: plan / stage / upload / other (ms)"""
+        ms = (C.c_float * len(CREATE_PARTS))()
+        rc = self._L.jdgpu_batch_create_ms(self._h, ms)
+        if rc:
+            raise _err(self._L, "jdgpu_batch_create_ms", rc)
+        return dict(zip(CREATE_PARTS, [float(x) for x in ms]))
 
     @property
     def total_pixels(self):

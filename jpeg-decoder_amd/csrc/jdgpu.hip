@@ -560,7 +560,8 @@ struct __attribute__((aligned(16))) BlkDesc {
 
 struct SegTables {
     const uint8_t *lut;     /* LDS copy of the lookup part of the image's tables, converted */
-    const jd_lut *glut;     /* the whole tables in global memory (canonical fallback) */
+    const jd_lut *glut;     /* the batch's distinct tables in global memory, whole (canonical fallback) ... */
+    const uint16_t *gidx;   /* ... and which of them the image's slots are (jd_image::lut_idx) */
     const BlkDesc *blk;     /* LDS */
     uint32_t bpm;
 };
@@ -582,7 +583,7 @@ __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDe
         if (__builtin_expect(first == JD_LUT_NOSUB, 0)) {
             uint32_t slot = isdc ? (desc.slots & 15u) : (desc.slots >> 4);
             asm volatile("" : "+v"(slot));   /* keeps the address arithmetic of this (very rare) path inside it */
-            const jd_sym s = jd_lut_lookup_canon(T.glut + slot, top >> 16);
+            const jd_sym s = jd_lut_lookup_canon(T.glut + T.gidx[slot], top >> 16);
             e = LIGHT ? light_entry(s.len, s.size, s.run, s.bad != 0, isdc) : write_entry(s.len, s.size, s.run, s.bad != 0, isdc);
         } else {
             const uint32_t rest = (top >> 16) & ((1u << (16 - JD_LUT_BITS)) - 1u);
@@ -859,21 +860,23 @@ __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTabl
     return JD_ST_PACK(p - valid, k, b);
 }
 
-/* copy the lookup part of nslots tables into LDS, resolved entries rewritten for the kernel's
- * decode loop (LIGHT or write form), and build the per-unit descriptors */
+/* copy the lookup part of the image's nslots tables (luts: the batch's distinct tables) into LDS,
+ * resolved entries rewritten for the kernel's decode loop (LIGHT or write form), and build the per-unit
+ * descriptors */
 template <bool LIGHT>
-__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *g_lut, const jd_image &im,
+__device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, const jd_lut *luts, const jd_image &im,
                                              uint32_t nslots = JD_LUT_SLOTS) {
-    constexpr uint32_t HOT32 = sizeof(jd_lut_hot) / 4, LUT32 = sizeof(jd_lut) / 4;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_lut);
+    constexpr uint32_t HOT32 = sizeof(jd_lut_hot) / 4;
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_lut);
     /* two entries per lane and round, not unrolled: this loop must not set the kernel's register count */
 #pragma unroll 1
     for (uint32_t slot = 0; slot < nslots; ++slot) {
-        const bool is_dc = g_lut[slot].is_dc != 0;
+        const jd_lut &g = luts[im.lut_idx[slot]];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&g);
+        const bool is_dc = g.is_dc != 0;
 #pragma unroll 1
         for (uint32_t i = threadIdx.x; i < HOT32; i += blockDim.x) {
-            const uint32_t v = src[slot * LUT32 + i];
+            const uint32_t v = src[i];
             dst[slot * HOT32 + i] = convert_entry<LIGHT>(v & 0xFFFFu, is_dc) | (convert_entry<LIGHT>(v >> 16, is_dc) << 16);
         }
     }
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
     const uint32_t n_segs = im.n_segs;
     if (!__syncthreads_or(wg.seg0 < n_segs)) return; /* seg_cap is an upper bound: trailing groups are empty */
     const jd_image &im0 = imgs[wgs[wg_index() * JD_WG_WAVES].img];
-    stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
+    stage_tables<true>(s_lut, s_blk, luts, im0);
     __syncthreads();
     if (wg.seg0 >= n_segs) return;
     /* a lane takes first_span consecutive segments: the first from a guessed start state, the
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
     const uint32_t span = im.first_span;   /* 1 in small images (jd_plan_build) */
     uint32_t seg = wg.seg0 + (threadIdx.x & 63u) * span;
     if (seg >= n_segs) return;
-    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts, im.lut_idx, s_blk, im.bpm};
     const uint8_t *const cimg = clean + im.clean_off;
     uint32_t prev_exit = 0;
 #pragma unroll 1
@@ -1039,12 +1042,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
     const uint32_t n_list = min(list_cnt[wg.img], im.n_segs);
     if (!__syncthreads_or(wg.seg0 < n_list)) return; /* the usual case from the second round on */
     const jd_image &im0 = imgs[wgs[wg_index() * JD_WG_WAVES].img];
-    stage_tables<true>(s_lut, s_blk, luts + im0.lut_off, im0);
+    stage_tables<true>(s_lut, s_blk, luts, im0);
     __syncthreads();
     if (wg.seg0 >= n_list) return;
     const uint32_t idx = wg.seg0 + (threadIdx.x & 63u);
     if (idx >= n_list) return;
-    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts + im.lut_off, s_blk, im.bpm};
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts, im.lut_idx, s_blk, im.bpm};
     const uint32_t seg = list[im.seg_off + idx];
     const uint32_t gs = im.seg_off + seg;
     /* a listed segment never starts an interval, so it has a predecessor.  That one may be on
@@ -1228,10 +1231,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     if (!__syncthreads_or(wg.seg0 < n_segs && mine)) return;
     const uint32_t lane = threadIdx.x, wlane = lane & 63u, wbase = lane & ~63u;
     const uint32_t seg = wg.seg0 + wlane / SUB, sub = wlane % SUB;
-    const jd_lut *const g_lut = luts + im.lut_off;
     {
         const jd_image &im0 = imgs[wgs[wg_index() * WAVES].img];
-        stage_tables<false>(s_lut, s_blk, luts + im0.lut_off, im0, SLOTS);
+        stage_tables<false>(s_lut, s_blk, luts, im0, SLOTS);
     }
     if (lane < 64) s_cm[lane] = c_zz_cm[lane];
     {
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
     }
     BitReader R = make_reader(clean + im.clean_off, active ? seg : wg.seg0, n_segs);
     R.init(active ? p : 0u);
-    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), g_lut, s_blk, 0u};
+    const SegTables T{reinterpret_cast<const uint8_t *>(s_lut), luts, im.lut_idx, s_blk, 0u};
     BlkDesc tb = s_blk[b];
     bool own = (k == 0); /* does this lane own the data unit it is in? */
     int dcv = 0;         /* NARROW: DC value of the unit in progress */
@@ -2101,6 +2103,7 @@ struct jdgpu_batch {
                          gather runs on the batch's stream, in front of its first decode) */
     bool redo;       /* the current pass is a repeat: kernels skip the images whose word in the redo list is 0 */
     bool timed;
+    float create_ms[JDGPU_NCREATE];   /* where the creation of this batch spent its time (jdgpu_batch_create_ms) */
 };
 
 static std::mutex g_mu;
@@ -2287,9 +2290,73 @@ static int stage_reserve(size_t bytes) {
     return JDGPU_OK;
 }
 
+/* Pinned host memory handed out to callers (jdgpu_pinned_alloc): a loader reads its files straight into
+ * such a region, and batch creation then uploads from where they lie -- one DMA of the span that holds the
+ * batch's scans (or whole files), no copy into the library's staging buffer.  That copy was 16 ms on 16
+ * threads per 4096 x 1080p batch and the reason a loader could not feed the GPU with a few threads. */
+struct PinnedRegion { uint8_t *base; size_t bytes; };
+static std::mutex g_pin_mu;
+static std::vector<PinnedRegion> g_pinned;
+
+extern "C" void *jdgpu_pinned_alloc(size_t bytes) {
+    if (ensure_device()) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(g_err, sizeof g_err, "hipHostMalloc(%zu bytes) failed", bytes);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back({static_cast<uint8_t *>(p), bytes ? bytes : 1});
+    return p;
+}
+extern "C" void jdgpu_pinned_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].base == p) { g_pinned[i] = g_pinned.back(); g_pinned.pop_back(); break; }
+    }
+    hipHostFree(p);
+}
+/* the registered region that holds [p, p + len), if any */
+static bool pinned_region_of(const void *p, size_t len, PinnedRegion *out) {
+    const uint8_t *q = static_cast<const uint8_t *>(p);
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const PinnedRegion &r : g_pinned)
+        if (q >= r.base && q + len <= r.base + r.bytes) { *out = r; return true; }
+    return false;
+}
+/* Do the n byte ranges all lie in ONE pinned region, and is the span from the first to the last of them
+ * worth a single upload (at most twice their sum: a batch that picks a few files out of a large arena
+ * goes through the staging buffer instead)?  lo / hi: the span. */
+template <class Range>
+static bool pinned_span(size_t n, Range range, const uint8_t **lo, const uint8_t **hi) {
+    const uint8_t *a = nullptr, *b = nullptr;
+    PinnedRegion reg{nullptr, 0};
+    size_t sum = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t *p; size_t len;
+        if (!range(i, &p, &len)) continue;
+        if (!reg.base && !pinned_region_of(p, len, &reg)) return false;
+        if (p < reg.base || p + len > reg.base + reg.bytes) return false;
+        if (!a || p < a) a = p;
+        if (!b || p + len > b) b = p + len;
+        sum += len;
+    }
+    if (!a || (size_t)(b - a) > 2 * sum + (1u << 20)) return false;
+    *lo = a; *hi = b;
+    return true;
+}
+
 /* set by jdgpu_batch_create_from_files around its call of jdgpu_batch_create: the device copy of
  * the files, which the new batch takes over (so that nothing has to wait for the gather kernel) */
 static thread_local uint8_t *g_adopt_files = nullptr;
+static thread_local float g_pre_ms[JDGPU_NCREATE] = {0, 0, 0, 0};   /* ... and what it spent before that call */
+/* One bulk upload at a time: two that share the PCIe link both take twice as long and end together, and
+ * the link then idles while both creations do their host work; one after the other, the second creation's
+ * host work hides behind the first one's upload (pipelined loader: 32 -> 27 ms per 4096 x 1080p batch) */
+static std::mutex g_upload_mu;
 
 #include "jdgpu_headers.inc"   /* device-side header parsing and scan gather (row f1) */
 
@@ -2315,10 +2382,17 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    for (int k = 0; k < JDGPU_NCREATE; ++k) { b->create_ms[k] = g_pre_ms[k]; g_pre_ms[k] = 0; }
     double t0 = now();
+    auto lap = [&](int part, const char *what) {
+        const double t1 = now();
+        b->create_ms[part] += (float)(t1 - t0);
+        if (trace) fprintf(stderr, "[jdgpu] %s %.1f ms\n", what, t1 - t0);
+        t0 = t1;
+    };
     TRY(jd_plan_build(descs, n, (flags & JDGPU_OUT_4BYTE) ? 4u : 3u, (flags & JDGPU_OUT_PITCHED) ? 1u : 0u, &b->plan, g_err, sizeof g_err));
     jd_plan &P = b->plan;
-    if (trace) { fprintf(stderr, "[jdgpu] plan %.1f ms\n", now() - t0); t0 = now(); }
+    lap(JDGPU_CREATE_PLAN, "plan");
     b->status.assign(n, 0);
     for (size_t i = 0; i < n; ++i) if (!P.img[i].ncomp) b->status[i] = JDGPU_IMG_UNSUPPORTED;
 
@@ -2328,7 +2402,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_clean, P.clean_bytes));
     TRY(dalloc(&b->d_pix, (size_t)P.pix_bytes + 256));
     TRY(dalloc(&b->d_img, n));
-    TRY(dalloc(&b->d_luts, n * JD_LUT_SLOTS));
+    TRY(dalloc(&b->d_luts, (size_t)P.n_luts));
     TRY(dalloc(&b->d_seg_info, (size_t)P.n_segs_cap + 1));
     TRY(dalloc(&b->d_st_in, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_st_exit, (size_t)P.n_segs_cap));
@@ -2355,51 +2429,95 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_ivl_u, (size_t)P.n_u));
     TRY(dalloc(&b->d_ivl_seg, (size_t)P.n_intervals));
     for (size_t i = 0; i < n; ++i) b->any_rst |= P.img[i].ncomp && P.img[i].ri_blocks != 0;
-    if (trace) { fprintf(stderr, "[jdgpu] device allocations %.1f ms\n", now() - t0); t0 = now(); }
+    lap(JDGPU_CREATE_OTHER, "device allocations");
 
-    if (!(flags & JDGPU_SCAN_ON_DEVICE)) {
-        std::lock_guard<std::mutex> lock(g_stage_mu);
-        TRY(stage_reserve(P.raw_bytes));
-        P.raw = g_stage; P.raw_owned = 0;
-        jd_plan_gather(&P, descs, n);
-        if (trace) { fprintf(stderr, "[jdgpu] gather %.1f ms\n", now() - t0); t0 = now(); }
-        HIPTRY(hipMemcpy(b->d_raw, P.raw, P.raw_bytes, hipMemcpyHostToDevice));
-        P.raw = nullptr;
-    }
-    HIPTRY(hipMemcpy(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_luts, P.luts, n * JD_LUT_SLOTS * sizeof(jd_lut), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_rpl, P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_fwg, P.fwg, (size_t)P.n_fwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice));
-    HIPTRY(hipMemcpy(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice));
-    if (trace) { fprintf(stderr, "[jdgpu] uploads (%.2f GB scan) %.1f ms\n", P.raw_bytes / 1e9, now() - t0); t0 = now(); }
-    if (flags & JDGPU_SCAN_ON_DEVICE) {
-        /* the scans already lie in device memory (jdgpu_parse_files_device): copied on the device,
-         * and waited for, so that the caller may release the files when this returns */
-        std::vector<uint64_t> src(n ? n : 1);
+    /* the scans.  (a) They lie in device memory already (JDGPU_SCAN_ON_DEVICE).  (b) They lie in ONE region of
+     * pinned host memory from jdgpu_pinned_alloc: the span that holds them goes up in one DMA from where it
+     * is, and the scans are picked out of it on the device.  (c) Anywhere else: gathered by host threads into
+     * the library's pinned staging buffer, one upload. */
+    std::vector<uint64_t> src;
+    bool on_device = (flags & JDGPU_SCAN_ON_DEVICE) != 0;
+    if (on_device) {
+        src.resize(n ? n : 1);
         for (size_t i = 0; i < n; ++i) src[i] = (uint64_t)(uintptr_t)descs[i].scan;
+    } else {
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        const bool span = pinned_span(n, [&](size_t i, const uint8_t **p, size_t *len) {
+            if (!P.img[i].ncomp) return false;
+            *p = descs[i].scan; *len = descs[i].scan_len;
+            return true;
+        }, &lo, &hi);
+        if (span) {
+            uint8_t *d_span = nullptr;
+            TRY(pool_alloc(reinterpret_cast<void **>(&d_span), (size_t)(hi - lo) + 16));
+            b->d_files = d_span;   /* released with the batch */
+            {
+                std::lock_guard<std::mutex> up(g_upload_mu);
+                HIPTRY(hipMemcpy(d_span, lo, (size_t)(hi - lo), hipMemcpyHostToDevice));
+            }
+            lap(JDGPU_CREATE_UPLOAD, "span upload");
+            src.resize(n ? n : 1);
+            for (size_t i = 0; i < n; ++i) src[i] = P.img[i].ncomp ? (uint64_t)(uintptr_t)(d_span + (descs[i].scan - lo)) : 0;
+            on_device = true;
+        } else {
+            std::lock_guard<std::mutex> lock(g_stage_mu);
+            TRY(stage_reserve(P.raw_bytes));
+            P.raw = g_stage; P.raw_owned = 0;
+            jd_plan_gather(&P, descs, n);
+            lap(JDGPU_CREATE_STAGE, "gather");
+            HIPTRY(hipMemcpy(b->d_raw, P.raw, P.raw_bytes, hipMemcpyHostToDevice));
+            P.raw = nullptr;
+            lap(JDGPU_CREATE_UPLOAD, "scan upload");
+        }
+    }
+    HIPTRY(hipMemcpyAsync(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice, b->stream));
+    if (P.n_luts) HIPTRY(hipMemcpyAsync(b->d_luts, P.luts, (size_t)P.n_luts * sizeof(jd_lut), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_rpl, P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_fwg, P.fwg, (size_t)P.n_fwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice, b->stream));
+    HIPTRY(hipMemcpyAsync(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
+    if (on_device) {
+        /* copied on the device into the raw buffer the unstuff stage reads (16-byte aligned starts, zeros after
+         * each scan), on the batch's own stream */
         TRY(dalloc(&b->d_scan_src, n));
-        HIPTRY(hipMemcpy(b->d_scan_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+        HIPTRY(hipMemcpyAsync(b->d_scan_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice, b->stream));
         HIPTRY(hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream));
         if (P.n_rwg) {
             hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, b->d_scan_src, b->d_raw);
             HIPTRY(hipGetLastError());
         }
-        /* waited for unless the batch owns the files (jdgpu_batch_create_from_files): the caller may
-         * release them when this returns.  Owned files stay until the batch goes: the gather is then
-         * simply the first thing on the batch's stream */
-        if (!b->d_files) HIPTRY(hipStreamSynchronize(b->stream));
-        if (trace) { fprintf(stderr, "[jdgpu] device gather %.1f ms\n", now() - t0); t0 = now(); }
     }
-    /* on the batch's own stream: ordered before its first decode without waiting for other batches */
-    HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
+    /* The output is cleared only where its content is not all written by a decode: padded rows
+     * (JDGPU_OUT_PITCHED: the padding is zero and never written) and images the plan rejected.  A failed
+     * image is zeroed when its status is known (jdgpu_batch_sync); clearing 25 GB per batch here cost
+     * 4.3 ms of the GPU, a fifth of a decode. */
+    if (flags & JDGPU_OUT_PITCHED) {
+        HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            if (!P.img[i].ncomp)
+                HIPTRY(hipMemsetAsync(b->d_pix + P.img[i].pix_off, 0, (size_t)P.img[i].stride * P.img[i].height * P.px_bytes, b->stream));
+    }
     HIPTRY(hipMemsetAsync(b->d_status, 0, (n ? n : 1) * 4, b->stream));
-    if (trace) { HIPTRY(hipStreamSynchronize(b->stream)); fprintf(stderr, "[jdgpu] output clear %.1f ms\n", now() - t0); }
+    /* Everything above reads host memory of this call (the plan's arrays, the caller's scans) or, with
+     * JDGPU_SCAN_ON_DEVICE, device memory the caller may release when this returns: wait for it.  The
+     * exception: files the batch owns (jdgpu_batch_create_from_files adopted them) and plan arrays, which live
+     * as long as the batch -- but the pageable plan arrays are staged by the runtime at enqueue time only when
+     * small; so wait in every case, it is the upload's duration and nothing else. */
+    HIPTRY(hipStreamSynchronize(b->stream));
+    lap(JDGPU_CREATE_UPLOAD, "uploads, device gather");
+    if (trace) fprintf(stderr, "[jdgpu]   (%.2f GB of scans, %u distinct Huffman tables)\n", P.raw_bytes / 1e9, P.n_luts);
     /* the host copies of the bulky arrays are not needed any more */
     free(P.luts); P.luts = nullptr;
     *out = b;
+    return JDGPU_OK;
+}
+
+extern "C" int jdgpu_batch_create_ms(const jdgpu_batch *b, float ms[JDGPU_NCREATE]) {
+    if (!b || !ms) return JDGPU_ERR_ARG;
+    memcpy(ms, b->create_ms, sizeof b->create_ms);
     return JDGPU_OK;
 }
 
@@ -2590,6 +2708,18 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         HIPCHK(hipStreamSynchronize(s));
     }
     for (size_t i = 0; i < P.n; ++i) b->status[i] = st[i] | (P.img[i].ncomp ? 0u : (uint32_t)JDGPU_IMG_UNSUPPORTED);
+    /* a failed image reads all zero (include/jpeg_gpu.h): the pixel kernel skipped it, so its region holds
+     * whatever the recycled buffer held; cleared here, where the failure is known, instead of clearing
+     * every batch's whole output at creation */
+    if (!(b->flags & JDGPU_OUT_PITCHED)) {
+        bool any = false;
+        for (size_t i = 0; i < P.n; ++i)
+            if (st[i] & (JDGPU_IMG_EOF | JDGPU_IMG_NOSYMBOL | JDGPU_IMG_RANGE)) {
+                HIPCHK(hipMemsetAsync(b->d_pix + P.img[i].pix_off, 0, (size_t)P.img[i].stride * P.img[i].height * P.px_bytes, b->stream));
+                any = true;
+            }
+        if (any) HIPCHK(hipStreamSynchronize(b->stream));
+    }
     if (b->timed) {
         for (int s = 0; s < 5; ++s) HIPCHK(hipEventElapsedTime(&b->ms[s], b->ev[s], b->ev[s + 1]));
         HIPCHK(hipEventElapsedTime(&b->ms[JDGPU_STAGE_TOTAL], b->ev[0], b->ev[5]));

@@ -133,7 +133,8 @@ typedef struct {
     uint32_t chunk_off;    /* index of its first raw chunk in the per-chunk arrays */
     uint32_t n_chunks;     /* raw chunks of JD_RAW_CHUNK bytes */
     uint32_t pix_mode;     /* JD_PIX_* fast path of the pixel kernel */
-    uint32_t lut_off;      /* index of the image's first jd_lut (JD_LUT_SLOTS each) */
+    uint16_t lut_idx[JD_LUT_SLOTS]; /* the image's table slots: indices into the batch's array of DISTINCT flattened
+                              tables (a batch mostly repeats a handful: the Annex K ones above all) */
     uint32_t mcus_x, mcus_y;
     uint16_t width, height;
     uint8_t  ncomp, bpm, maxH, maxV;
@@ -211,7 +212,8 @@ typedef struct { uint32_t img, chunk; } jd_raw_wg;               /* JD_RAW_CHUNK
 typedef struct {
     size_t n;
     jd_image *img;           /* [n] */
-    jd_lut *luts;            /* [n * JD_LUT_SLOTS] */
+    jd_lut *luts;            /* [n_luts]: the distinct (class, counts, symbols) of the batch, flattened once each */
+    uint32_t n_luts;
     uint8_t *raw;            /* concatenated stuffed scans, each padded to 16 B: staging memory set by the caller
                                 before jd_plan_gather(), not owned unless raw_owned */
     int raw_owned;

@@ -88,35 +88,82 @@ int jd_lut_build(const jdgpu_huff_spec *spec, int is_dc, jd_lut *lut) {
     return 0;
 }
 
-/* Batches mostly repeat a handful of Huffman tables (the Annex K ones above all): flatten each
- * distinct (class, counts, symbols) once per plan and copy the result. */
-#define JD_LUT_CACHE 32
+/* Batches mostly repeat a handful of Huffman tables (the Annex K ones above all): every distinct
+ * (class, counts, symbols) of a plan is flattened once, into plan->luts, and the images hold indices.
+ * (Until round 3 every image carried its own copy of its six tables: 77 MB to build, upload and read
+ * for a 4096-image batch.)  Open addressing over a hash of the specification; no limit on the number of
+ * distinct tables but the 16-bit index. */
 typedef struct {
-    unsigned n;
-    int is_dc[JD_LUT_CACHE], rc[JD_LUT_CACHE];
-    const jdgpu_huff_spec *spec[JD_LUT_CACHE];
-    const jd_lut *lut[JD_LUT_CACHE];
-} lut_cache;
+    uint32_t cap;                      /* power of two */
+    int32_t *slot;                     /* index into lut[] or -1 */
+    const jdgpu_huff_spec **spec;      /* per distinct table: where its specification lies (caller's descriptors) */
+    int *rc;                           /* jd_lut_build's verdict */
+    uint32_t lut_cap;
+} lut_index;
 
-/* *id: which distinct table of the plan this is (-1: the cache is full, identity unknown) */
-static int lut_build_cached(lut_cache *c, const jdgpu_huff_spec *spec, int is_dc, jd_lut *out, int *id) {
-    for (unsigned i = 0; i < c->n; ++i)
-        if (c->is_dc[i] == is_dc && (c->spec[i] == spec || memcmp(c->spec[i], spec, sizeof *spec) == 0)) {
-            memcpy(out, c->lut[i], sizeof *out);
-            *id = (int)i;
-            return c->rc[i];
-        }
-    int rc = jd_lut_build(spec, is_dc, out);
-    *id = -1;
-    if (c->n < JD_LUT_CACHE) {
-        c->is_dc[c->n] = is_dc; c->rc[c->n] = rc; c->spec[c->n] = spec; c->lut[c->n] = out; *id = (int)c->n; ++c->n;
-    }
-    return rc;
+static uint32_t spec_hash(const jdgpu_huff_spec *spec, int is_dc) {
+    uint32_t h = 2166136261u ^ (uint32_t)is_dc;
+    const uint8_t *p = (const uint8_t *)spec;
+    unsigned used = 16;
+    for (unsigned i = 0; i < 16; ++i) used += spec->counts[i];   /* symbols beyond the counted ones do not matter */
+    if (used > sizeof *spec) used = sizeof *spec;
+    for (unsigned i = 0; i < used; ++i) h = (h ^ p[i]) * 16777619u;
+    return h;
 }
+static int spec_equal(const jdgpu_huff_spec *a, const jdgpu_huff_spec *b) {
+    if (a == b) return 1;
+    if (memcmp(a->counts, b->counts, 16)) return 0;
+    unsigned used = 0;
+    for (unsigned i = 0; i < 16; ++i) used += a->counts[i];
+    return memcmp(a->symbols, b->symbols, used > 256 ? 256 : used) == 0;
+}
+
+/* the index of (spec, is_dc) among the plan's distinct tables, flattening it on first sight; -1: out of
+ * memory or more than 65535 distinct tables; *rc: jd_lut_build's verdict on the table */
+static int32_t lut_intern(lut_index *ix, jd_plan *P, const jdgpu_huff_spec *spec, int is_dc, int *rc) {
+    if (ix->cap == 0 || 2u * (P->n_luts + 1u) > ix->cap) {   /* grow and rehash */
+        uint32_t cap = ix->cap ? ix->cap * 2u : 64u;
+        int32_t *slot = malloc(cap * sizeof *slot);
+        if (!slot) return -1;
+        for (uint32_t i = 0; i < cap; ++i) slot[i] = -1;
+        for (uint32_t k = 0; k < P->n_luts; ++k) {
+            uint32_t h = spec_hash(ix->spec[k], (int)P->luts[k].is_dc) & (cap - 1u);
+            while (slot[h] >= 0) h = (h + 1u) & (cap - 1u);
+            slot[h] = (int32_t)k;
+        }
+        free(ix->slot); ix->slot = slot; ix->cap = cap;
+    }
+    uint32_t h = spec_hash(spec, is_dc) & (ix->cap - 1u);
+    for (; ix->slot[h] >= 0; h = (h + 1u) & (ix->cap - 1u)) {
+        const int32_t k = ix->slot[h];
+        if ((int)P->luts[k].is_dc == is_dc && spec_equal(ix->spec[k], spec)) { *rc = ix->rc[k]; return k; }
+    }
+    if (P->n_luts >= 65535u) return -1;
+    if (P->n_luts == ix->lut_cap) {
+        uint32_t cap = ix->lut_cap ? ix->lut_cap * 2u : 16u;
+        jd_lut *l = realloc(P->luts, cap * sizeof *l);
+        if (!l) return -1;
+        P->luts = l;
+        const jdgpu_huff_spec **sp = realloc(ix->spec, cap * sizeof *sp);
+        if (!sp) return -1;
+        ix->spec = sp;
+        int *r = realloc(ix->rc, cap * sizeof *r);
+        if (!r) return -1;
+        ix->rc = r;
+        ix->lut_cap = cap;
+    }
+    const int32_t k = (int32_t)P->n_luts++;
+    ix->rc[k] = jd_lut_build(spec, is_dc, &P->luts[k]);
+    ix->spec[k] = spec;
+    ix->slot[h] = k;
+    *rc = ix->rc[k];
+    return k;
+}
+static void lut_index_free(lut_index *ix) { free(ix->slot); free(ix->spec); free(ix->rc); memset(ix, 0, sizeof *ix); }
 
 /* What the Huffman kernels keep in LDS for a work-group: the lookup tables of the slots and the
  * per-unit descriptors.  Images with equal keys may share a work-group (one wave each). */
-typedef struct { int8_t lut_id[JD_LUT_SLOTS]; uint8_t bpm, comp[JD_MAX_BPM], dc[JD_MAX_BPM], ac[JD_MAX_BPM]; } table_key;
+typedef struct { uint16_t lut_idx[JD_LUT_SLOTS]; uint8_t nslots, bpm, comp[JD_MAX_BPM], dc[JD_MAX_BPM], ac[JD_MAX_BPM]; } table_key;
 
 /* ---- gathering the scans into one staging buffer ------------------------------------------------
  * 1.5 GB for a 4096 x 1080p batch: a single thread spends ~300 ms in first-touch page faults and
@@ -162,10 +209,10 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
     P->px_bytes = px_bytes;
     P->pitched = pitched;
     P->img = calloc(n ? n : 1, sizeof *P->img);
-    P->luts = calloc((n ? n : 1) * JD_LUT_SLOTS, sizeof *P->luts);
-    if (!P->img || !P->luts) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
+    P->luts = NULL; P->n_luts = 0;
+    if (!P->img) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
 
-    lut_cache cache; cache.n = 0;
+    lut_index lix; memset(&lix, 0, sizeof lix);
     table_key *keys = calloc(n ? n : 1, sizeof *keys);
     if (!keys) { seterr(err, errlen, "out of host memory"); return JDGPU_ERR_NOMEM; }
     size_t raw = 0, clean = 0, pix = 0;
@@ -201,7 +248,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
             if (maxH % d->comp[c].H || maxV % d->comp[c].V) ok = 0;
         im->width = d->width; im->height = d->height;
         im->raw_off = raw; im->clean_off = clean; im->pix_off = pix; im->blk_off = blk;
-        im->seg_off = segs; im->ivl_off = ivls; im->lut_off = (uint32_t)(i * JD_LUT_SLOTS);
+        im->seg_off = segs; im->ivl_off = ivls;
         /* row stride in pixels.  Pitched: 3-byte pixels and the 1-byte rows of a plane need a multiple of
          * 256 pixels for rows on 256-byte boundaries, 4-byte pixels a multiple of 64 */
         im->stride = pitched ? (uint32_t)align_up(d->width, px_bytes == 4 ? 64 : 256) : d->width;
@@ -221,17 +268,15 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         unsigned nslots = 0, b = 0;
         for (unsigned c = 0; c < nc; ++c) {
             unsigned td = d->comp[c].Td, ta = d->comp[c].Ta;
-            int id;
-            if (slot_of[0][td] < 0) {
-                slot_of[0][td] = (int)nslots;
-                if (lut_build_cached(&cache, &d->huff[0][td], 1, &P->luts[im->lut_off + nslots], &id)) ok = 0;
-                keys[i].lut_id[nslots] = (int8_t)(id < 0 ? -1 : id + 1);
-                ++nslots;
-            }
-            if (slot_of[1][ta] < 0) {
-                slot_of[1][ta] = (int)nslots;
-                if (lut_build_cached(&cache, &d->huff[1][ta], 0, &P->luts[im->lut_off + nslots], &id)) ok = 0;
-                keys[i].lut_id[nslots] = (int8_t)(id < 0 ? -1 : id + 1);
+            for (int cls = 0; cls < 2; ++cls) {   /* DC table, then AC table of the component */
+                const unsigned t = cls ? ta : td;
+                if (slot_of[cls][t] >= 0) continue;
+                int brc = 0;
+                const int32_t id = lut_intern(&lix, P, &d->huff[cls][t], !cls, &brc);
+                if (id < 0) { lut_index_free(&lix); free(keys); seterr(err, errlen, "out of host memory (Huffman tables)"); return JDGPU_ERR_NOMEM; }
+                if (brc) ok = 0;
+                slot_of[cls][t] = (int)nslots;
+                im->lut_idx[nslots] = keys[i].lut_idx[nslots] = (uint16_t)id;
                 ++nslots;
             }
             im->comp_H[c] = d->comp[c].H; im->comp_V[c] = d->comp[c].V;
@@ -244,8 +289,9 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
                 }
         }
         if (!ok) { im->ncomp = 0; continue; }
+        for (unsigned k = nslots; k < JD_LUT_SLOTS; ++k) im->lut_idx[k] = im->lut_idx[0];   /* unused slots: any valid table */
         im->bpm = (uint8_t)b;
-        keys[i].bpm = (uint8_t)b;
+        keys[i].bpm = (uint8_t)b; keys[i].nslots = (uint8_t)nslots;
         {
             int std_ids = nc == 3 && d->comp[0].id == 1 && d->comp[1].id == 2 && d->comp[2].id == 3;
             int c11 = d->comp[1].H == 1 && d->comp[1].V == 1 && d->comp[2].H == 1 && d->comp[2].V == 1;
@@ -291,6 +337,7 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         uint32_t strip = JD_STRIP_MCUS(maxH);
         np += im->mcus_y * ((im->mcus_x + strip - 1) / strip); /* single-row strips: regrouped below */
     }
+    lut_index_free(&lix);
     P->raw_bytes = raw + 64; P->clean_bytes = clean + JD_SEG_BYTES * 2;
     P->n_segs_cap = segs; P->n_intervals = ivls; P->total_blocks = blk; P->pix_bytes = pix;
     /* rows per pixel work-group: as many as leave ~8 work-groups per CU slot round */
@@ -324,12 +371,10 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         for (size_t i = 0; i < n; ++i) {
             grp[i] = -1;
             if (!P->img[i].ncomp) continue;
-            int known = 1;
-            for (unsigned k = 0; k < JD_LUT_SLOTS; ++k) known &= keys[i].lut_id[k] >= 0;
             int32_t g = -1;
-            for (uint32_t q = 0; known && q < ngrp; ++q)
+            for (uint32_t q = 0; q < ngrp; ++q)
                 if (memcmp(&keys[rep[q]], &keys[i], sizeof keys[i]) == 0) { g = (int32_t)q; break; }
-            if (g < 0 && known && ngrp < MAXG) { rep[ngrp] = i; g = (int32_t)ngrp++; }
+            if (g < 0 && ngrp < MAXG) { rep[ngrp] = i; g = (int32_t)ngrp++; }
             grp[i] = g < 0 ? (int32_t)(MAXG + nsolo++) : g;   /* solo images: a group each */
             cnt[grp[i]] += (P->img[i].seg_cap + 63u) / 64u;
         }
@@ -337,11 +382,8 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
          * table slots (2 DC + 2 AC, the usual case): 2 x (64 KB of unit buffers + 11 KB of tables)
          * fit a CU's LDS, 16 waves per CU instead of 12 */
         uint32_t max_slots = 0;
-        for (size_t i = 0; i < n; ++i) {
-            uint32_t ns = 0;
-            for (unsigned k = 0; k < JD_LUT_SLOTS; ++k) ns += keys[i].lut_id[k] != 0;
-            if (P->img[i].ncomp && ns > max_slots) max_slots = ns;
-        }
+        for (size_t i = 0; i < n; ++i)
+            if (P->img[i].ncomp && keys[i].nslots > max_slots) max_slots = keys[i].nslots;
         uint32_t all_waves = 0;
         for (uint32_t g = 0; g < MAXG + nsolo; ++g) all_waves += cnt[g];
         /* ... and only when there are enough waves to fill the chip twice over with them (a batch

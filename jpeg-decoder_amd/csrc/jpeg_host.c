@@ -147,6 +147,44 @@ static int seg_huffman(jpeg_info *ji, const uint8_t *d, unsigned n) {
     return 0;
 }
 
+/* The same for the batch parser, which needs no tree: the DHT payload IS the flat description
+ * (counts per length + symbols in code order) the descriptor carries, whenever the table is an ordinary
+ * prefix code -- the canonical assignment never runs out of codes of a length and there are at most 256
+ * symbols.  Then building the tree (a calloc per code bit) and flattening it again gives back these very
+ * bytes: leaves in code order are leaves in (length, index) order.  A table that is not (the reference's
+ * builder wraps around and overwrites, src/hufftree.c:18-41; what such a table means is defined by that
+ * tree) sets `fallback`, and the file goes through the tree path.  27 -> ~3 us per file. */
+typedef struct { jdgpu_huff_spec spec[2][4]; uint8_t defined[2][4]; int fallback; } flat_tables;
+
+static int seg_huffman_flat(flat_tables *ft, const uint8_t *d, unsigned n) {
+    if (n < 1) return -1;
+    for (size_t at = 0; at < n;) {
+        unsigned cls = d[at] >> 4, id = d[at] & 15u;
+        if (cls > 1 || id > 3) return -1;
+        if (at + 17 > n) return -1;
+        size_t total = 0;
+        unsigned code = 0;
+        for (unsigned l = 0; l < 16; ++l) {
+            const unsigned cnt = d[at + 1 + l];
+            total += cnt;
+            code += cnt;
+            if (code > (1u << (l + 1))) ft->fallback = 1;   /* more codes of this length than exist */
+            code <<= 1;
+        }
+        if (at + 17 + total > n) return -1;
+        if (total > 256) ft->fallback = 1;
+        if (!ft->fallback) {
+            jdgpu_huff_spec *sp = &ft->spec[cls][id];
+            memset(sp, 0, sizeof *sp);
+            memcpy(sp->counts, d + at + 1, 16);
+            memcpy(sp->symbols, d + at + 17, total);
+            ft->defined[cls][id] = total != 0;
+        }
+        at += 17 + total;
+    }
+    return 0;
+}
+
 static int seg_quant(jpeg_info *ji, const uint8_t *d, unsigned n) {
     if (n == 0 || n % 65u) return -1;
     for (; n; n -= 65, d += 65) {
@@ -179,7 +217,7 @@ static int seg_scan(scan_info *si, const jpeg_info *ji, const uint8_t *d, unsign
 }
 
 /* the marker loop of src/jpeg.c:23-58: SOI, then {marker, length, payload} until SOS */
-static int read_header(jpeg_info *ji, scan_info *si, source *s) {
+static int read_header(jpeg_info *ji, scan_info *si, source *s, flat_tables *ft /* NULL: build the trees */) {
     static _Thread_local uint8_t payload[65536];
     memset(ji, 0, sizeof *ji);
     memset(si, 0, sizeof *si);
@@ -199,7 +237,7 @@ static int read_header(jpeg_info *ji, scan_info *si, source *s) {
         if (src_read(s, payload, n) != n) return -1;
         int rc = 0;
         if (marker == M_SOF0) rc = seg_frame(ji, payload, n);
-        else if (marker == M_DHT) rc = seg_huffman(ji, payload, n);
+        else if (marker == M_DHT) rc = ft ? seg_huffman_flat(ft, payload, n) : seg_huffman(ji, payload, n);
         else if (marker == M_DQT) rc = seg_quant(ji, payload, n);
         else if (marker == M_DRI) { if (n >= 2) ji->restartInterval = (unsigned short)(payload[0] << 8 | payload[1]); }
         else if (marker == M_SOS) rc = seg_scan(si, ji, payload, n);
@@ -211,7 +249,7 @@ static int read_header(jpeg_info *ji, scan_info *si, source *s) {
 
 int jpeg_read_info(jpeg_info *jpegInfo, scan_info *scanInfo, FILE *fp) {
     source s = {fp, NULL, 0, 0, 0};
-    int rc = read_header(jpegInfo, scanInfo, &s);
+    int rc = read_header(jpegInfo, scanInfo, &s, NULL);
     return rc ? -1 : 0;
 }
 
@@ -223,7 +261,7 @@ void jpeg_free(jpeg_info *info) {
 /* ---- jpeg_info + scan_info + bytes -> flat descriptor ------------------------------------------ */
 
 static int desc_from_info(jdgpu_image_desc *d, const jpeg_info *ji, const scan_info *si,
-                          const uint8_t *scan, size_t scan_len) {
+                          const uint8_t *scan, size_t scan_len, const flat_tables *ft /* NULL: flatten the trees */) {
     memset(d, 0, sizeof *d);
     d->scan = scan; d->scan_len = scan_len;
     d->width = ji->width; d->height = ji->height;
@@ -239,6 +277,12 @@ static int desc_from_info(jdgpu_image_desc *d, const jpeg_info *ji, const scan_i
         d->comp[i].Ta = si->componentInfo[i].ACHuffmanTableID;
     }
     memcpy(d->quant, ji->quantizationTables, sizeof d->quant);
+    if (ft) {
+        for (int c = 0; c < 2; ++c)
+            for (int t = 0; t < 4; ++t)
+                if (ft->defined[c][t]) { d->huff[c][t] = ft->spec[c][t]; d->huff_defined[c][t] = 1; }
+        return 0;
+    }
     for (int c = 0; c < 2; ++c)
         for (int t = 0; t < 4; ++t) {
             const huffnode *root = &ji->huffmanTables[c][t];
@@ -253,9 +297,22 @@ static int desc_from_info(jdgpu_image_desc *d, const jpeg_info *ji, const scan_i
 int jdgpu_parse_file(const uint8_t *file, size_t len, jdgpu_image_desc *desc) {
     jpeg_info ji;
     scan_info si;
+    {
+        /* without trees (see seg_huffman_flat); a table that is no ordinary prefix code sends the file
+         * through the tree path below, whose result defines what such a table means */
+        flat_tables ft;
+        memset(ft.defined, 0, sizeof ft.defined);
+        ft.fallback = 0;
+        source s = {NULL, file, len, 0, 0};
+        int rc = read_header(&ji, &si, &s, &ft);
+        if (!ft.fallback) {
+            if (!rc) desc_from_info(desc, &ji, &si, file + s.pos, len - s.pos, &ft);
+            return rc ? JDGPU_ERR_HEADER : JDGPU_OK;
+        }
+    }
     source s = {NULL, file, len, 0, 0};
-    int rc = read_header(&ji, &si, &s);
-    if (!rc) desc_from_info(desc, &ji, &si, file + s.pos, len - s.pos);
+    int rc = read_header(&ji, &si, &s, NULL);
+    if (!rc) desc_from_info(desc, &ji, &si, file + s.pos, len - s.pos, NULL);
     jpeg_free(&ji);
     return rc ? JDGPU_ERR_HEADER : JDGPU_OK;
 }
@@ -325,7 +382,7 @@ void jpeg_read_image(pixel *img, const jpeg_info *info, const scan_info *scanInf
     if (ferror(fp)) die("Could not read file."); /* src/bitstream.c:16 */
 
     jdgpu_image_desc d;
-    desc_from_info(&d, info, scanInfo, buf, n);
+    desc_from_info(&d, info, scanInfo, buf, n, NULL);
     jdgpu_batch *b = NULL;
     int rc = jdgpu_batch_create(&d, 1, JDGPU_OUT_YCBCR, &b);
     if (!rc) rc = jdgpu_batch_decode(b);

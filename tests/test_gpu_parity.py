@@ -1176,6 +1176,19 @@ def test_batch_from_files_equals_batch_from_descriptors(pkg, dec):
                 continue
             assert np.array_equal(out.qcoef(i), ref.qcoef(i)), i
             assert np.array_equal(out.pixels(i), ref.pixels(i)), i
+        # the same files in one region of pinned host memory (jdgpu_pinned_alloc): uploaded from where they lie, as
+        # one span, by both creation calls -- same results, and no staging copy (create_ms()["stage"] == 0)
+        arena = pkg.Arena(files)
+        for via in (pkg.Batch.from_files(arena, flags), pkg.Batch(pkg.parse_many(arena, strict=False), flags)):
+            via.decode()
+            assert via.create_ms()["stage"] == 0.0 and via.create_ms()["upload"] > 0.0
+            for i in range(len(files)):
+                assert via.status(i) == ref.status(i), i
+                if i not in bad:
+                    assert np.array_equal(via.qcoef(i), ref.qcoef(i)) and np.array_equal(via.pixels(i), ref.pixels(i)), i
+            via.close()
+        arena.close()
+        assert ref.create_ms()["stage"] > 0.0            # ordinary host memory: gathered into the staging buffer
         # the debug read-back of the unstuffed stream works on a batch that keeps no descriptors too
         for i in (0, len(files) - 1):
             a, b = out.segments(i), ref.segments(i)
