@@ -237,6 +237,7 @@ unsigned jdgpu_segment_bytes(void);
  * the device for image i: each restart interval padded with 0xFF to a whole segment, segments one
  * after the other; seg_info[i]: bit 31 = first segment of an interval, low 16 bits = valid bits in
  * the segment (the format of the tests' host statement, csrc/host_hooks.h).  Returns the segment count. */
+long jdgpu_batch_debug_states(jdgpu_batch *b, size_t i, uint32_t *st_in, uint32_t *st_exit, size_t cap);
 long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *clean, size_t clean_cap,
                                 uint32_t *seg_info, size_t seg_cap);
 

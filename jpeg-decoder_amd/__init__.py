@@ -32,7 +32,7 @@ EXPORTS = [
     "jdgpu_batch_total_blocks", "jdgpu_batch_total_scan_bytes", "jdgpu_batch_image_blocks",
     "jdgpu_batch_read_pixels", "jdgpu_batch_pixel_bytes", "jdgpu_batch_pixel_pitch", "jdgpu_batch_device_pixels", "jdgpu_batch_read_coefficients",
     "jdgpu_batch_stage_ms", "jdgpu_batch_retries", "jdgpu_batch_repair_counts", "jdgpu_ycbcr_to_rgb", "jdgpu_ycbcr_to_rgb_noalloc", "jdgpu_noalloc_max_bytes", "jdgpu_rgb_to_ycbcr", "jdgpu_image_format",
-    "jdgpu_batch_debug_segments", "jdgpu_segment_bytes", "jdgpu_pinned_alloc", "jdgpu_pinned_free", "jdgpu_batch_create_ms",
+    "jdgpu_batch_debug_segments", "jdgpu_batch_debug_states", "jdgpu_segment_bytes", "jdgpu_pinned_alloc", "jdgpu_pinned_free", "jdgpu_batch_create_ms",
     # include/jpeg.h, include/image.h
     "jpeg_read_info", "jpeg_read_image", "jpeg_free",
     "image_print", "image_ycbcr_to_rgb", "image_rgb_to_ycbcr",
@@ -125,6 +125,8 @@ def lib():
     L.jdgpu_image_format.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, sz, C.POINTER(sz)]
     L.jdgpu_batch_debug_segments.argtypes = [vp, sz, vp, sz, vp, sz]
     L.jdgpu_batch_debug_segments.restype = C.c_long
+    L.jdgpu_batch_debug_states.argtypes = [vp, sz, vp, vp, sz]
+    L.jdgpu_batch_debug_states.restype = C.c_long
     L.jdgpu_pinned_alloc.argtypes = [sz]
     L.jdgpu_pinned_alloc.restype = vp
     L.jdgpu_pinned_free.argtypes = [vp]
@@ -396,6 +398,14 @@ class Batch:
         if n < 0:
             raise _err(self._L, "jdgpu_batch_debug_segments", n)
         return clean[:n * sb].copy(), seg[:n].copy()
+
+    def states(self, i, cap=1 << 20):
+        """(start states, exit states) of image i's segments as last decoded (development aid)"""
+        a, b = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        n = self._L.jdgpu_batch_debug_states(self._h, i, a.ctypes.data, b.ctypes.data, cap)
+        if n < 0:
+            raise _err(self._L, "jdgpu_batch_debug_states", n)
+        return a[:n].copy(), b[:n].copy()
 
     def stage_ms(self):
         ms = (C.c_float * len(STAGES))()

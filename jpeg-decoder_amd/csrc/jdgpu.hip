@@ -2673,6 +2673,7 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
         bool unsynced = false;
         for (size_t i = 0; i < P.n; ++i) unsynced |= (st[i] & JDGPU_IMG_UNSYNCED) != 0;
         if (!unsynced) break;
+        if (getenv("JDGPU_TEST_NO_RETRY")) break;   /* development aid (tools/guess_stats.py): leave the first pass's states as they are */
         if (attempt > 8) { snprintf(g_err, sizeof g_err, "segment chain did not converge"); return JDGPU_ERR_NOT_CONVERGED; }
         /* the chain of start states was still broken after the built-in repair rounds: repeat
          * them until a round lists nothing (every round mends at least the first break of each
@@ -2821,6 +2822,18 @@ extern "C" long jdgpu_batch_debug_segments(jdgpu_batch *b, size_t i, uint8_t *cl
             for (uint32_t o = 0; o < JD_SEG_BYTES; ++o) clean[(size_t)s * JD_SEG_BYTES + o] = t[clean_byte_addr(s, o)];
     }
     HIPCHK(hipMemcpy(seg_info, b->d_seg_info + im.seg_off, (size_t)im.n_segs * 4, hipMemcpyDeviceToHost));
+    return (long)im.n_segs;
+}
+
+/* development aid: the start state each segment of image i was last decoded from and the exit state it
+ * reached (packed: bits 5:0 overshoot, 12:6 zigzag index, 18:13 data unit of the MCU, 19 error seen) */
+extern "C" long jdgpu_batch_debug_states(jdgpu_batch *b, size_t i, uint32_t *st_in, uint32_t *st_exit, size_t cap) {
+    if (!b || i >= b->plan.n || !st_in || !st_exit) return JDGPU_ERR_ARG;
+    jd_image im;
+    HIPCHK(hipMemcpy(&im, b->d_img + i, sizeof im, hipMemcpyDeviceToHost));
+    if ((size_t)im.n_segs > cap) return JDGPU_ERR_ARG;
+    HIPCHK(hipMemcpy(st_in, b->d_st_in + im.seg_off, (size_t)im.n_segs * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st_exit, b->d_st_exit + im.seg_off, (size_t)im.n_segs * 4, hipMemcpyDeviceToHost));
     return (long)im.n_segs;
 }
 

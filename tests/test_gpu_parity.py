@@ -1314,6 +1314,18 @@ def test_failed_images_stay_zero_when_the_batch_needs_a_second_pass(pkg, dec, or
     assert failed >= 8
 
 
+def test_short_soak_of_random_streams(pkg):
+    """tools/soak.py, short: 768 seeded random streams -- sizes 1..300, every layout (the five with an
+    instantiation, factor 4, every luma H x V of 1..4), qualities 1..100, restart intervals, noise and
+    flat content, 15 % with a damaged scan -- in batches of 256 in three output layouts, half of the batches
+    made from whole files with the headers parsed on the device: status class, coefficients and pixels of
+    every stream against the oracle.  (The long runs are in DESIGN.md: ~60 000 streams, 0 mismatches.)"""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "soak.py"), "768", "20261111", "300"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "768 streams" in r.stdout and " 0 mismatches" in r.stdout.strip().splitlines()[-1]
+
+
 def test_one_process_one_device(pkg, dec):
     """jdgpu_init: idempotent for the bound device, refuses another one (process-wide buffer cache,
     staging buffer and constants belong to the first) -- checked before the range check, so the
