@@ -527,6 +527,20 @@ __global__ __launch_bounds__(256) void k_unstuff_scatter(const jd_image *__restr
  */
 #define LE_WIDE 0x1000u
 #define LE_BAD  0x2000u
+/* A light AC entry may stand for SEVERAL symbols (round 3): where the first symbol of a 10-bit window is an
+ * ordinary AC symbol (not an end of block, no large magnitude) and the bits behind it hold further whole AC
+ * symbols, the entry carries the bits and the index advance of all of them (JD_PAIR_MAX at most; the name
+ * says pair because most are).  The light decodes read no AC magnitudes, so nothing else of the group is
+ * needed -- as long as no symbol but the last ends the data unit.  The group is built so that all but its
+ * last symbol advance k by at most 16 together; while k < JD_PAIR_KMAX = 64 - 17 that cannot reach 64, and
+ * decoding the group at once IS decoding one symbol after the other, on any bit pattern.  At
+ * k >= JD_PAIR_KMAX (a few per cent of the steps at quality 85) the step takes the single-symbol entry from
+ * the table in global memory.  1080p 4:2:0 q85 has 5.2 bits per symbol. */
+#define LE_PAIR 0x4000u
+#define JD_PAIR_KMAX 47u
+#ifndef JD_PAIR_MAX
+#define JD_PAIR_MAX 3u
+#endif
 
 __device__ __forceinline__ uint32_t kinc_of(uint32_t size, uint32_t run, bool is_dc) {
     const uint32_t zero = run == 15u ? 16u : 64u;  /* ZRL skips 16, any other (r, 0) ends the block */
@@ -548,6 +562,22 @@ __device__ __forceinline__ uint32_t convert_entry(uint32_t e, bool is_dc) {
     const bool bad = (e & 0x2000u) != 0;
     return LIGHT ? light_entry(len, size, run, bad, is_dc) : write_entry(len, size, run, bad, is_dc);
 }
+/* light entry of primary index idx of an AC table, a pair where one fits (LE_PAIR above); e1: the single
+ * entry of idx, primary: the table's first level in global memory (read for the second symbol) */
+__device__ __forceinline__ uint32_t pair_entry(uint32_t e1, uint32_t idx, const uint16_t *primary) {
+    if (e1 & (JD_LUT_LINK | LE_BAD | LE_WIDE)) return e1;
+    uint32_t tot = e1 & 31u, kinc = (e1 >> 5) & 127u, n = 1;
+    /* kinc <= 16 here means: no symbol of the group so far is an end of block, and all of them together
+     * leave k below 64 when they start below JD_PAIR_KMAX */
+    while (n < JD_PAIR_MAX && kinc <= 16u && tot < JD_LUT_BITS) {
+        const uint32_t idx2 = (idx << tot) & ((1u << JD_LUT_BITS) - 1u);   /* the bits behind the group, zeros where the window ends */
+        const uint32_t e2 = convert_entry<true>(primary[idx2], false);
+        if (e2 & (JD_LUT_LINK | LE_BAD | LE_WIDE)) break;
+        if (tot + (e2 & 31u) > JD_LUT_BITS) break;                /* the next symbol is not whole inside the window */
+        tot += e2 & 31u; kinc += (e2 >> 5) & 127u; ++n;
+    }
+    return n == 1u ? e1 : (tot | (kinc << 5) | LE_PAIR);
+}
 
 /* per data unit of the MCU, in LDS: byte offsets of the unit's DC / AC table in the LDS copy,
  * slots = dc slot | ac slot << 4 (canonical fallback only), nb = the unit after it in the MCU;
@@ -568,8 +598,8 @@ struct SegTables {
 
 /* one symbol lookup against the LDS tables: desc = the unit's BlkDesc, isdc selects its DC or AC
  * table.  Returns the resolved (light or write) entry. */
-template <bool LIGHT>
-__device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top) {
+template <bool LIGHT, bool PAIRS = false>
+__device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDesc &desc, bool isdc, uint32_t top, uint32_t kk = 0u /* PAIRS: the zigzag index */) {
     const uint32_t off = isdc ? desc.dc_off : desc.ac_off;
     /* v_bfe_u32 + v_lshl_add_u32 (through asm: the compiler folds the two shifts of the C form into
      * shift + mask + add); the entry is read zero-extended, link entries are the ones whose 16-bit
@@ -578,6 +608,12 @@ __device__ __forceinline__ uint32_t lookup_entry(const SegTables &T, const BlkDe
     asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(idx) : "v"(top), "n"(32 - JD_LUT_BITS), "n"(JD_LUT_BITS));
     uint32_t e = *reinterpret_cast<const uint16_t *>(T.lut + (idx * 2u + off));
     asm("" : "+v"(e));   /* hides the 16-bit origin, or the compare below becomes a 16-bit one plus a mask */
+    if (PAIRS && __builtin_expect((e & LE_PAIR) != 0u && kk >= JD_PAIR_KMAX, 0)) {
+        /* the first symbol of the pair may end the data unit: the single entry, from global memory (rare) */
+        uint32_t slot = desc.slots >> 4;
+        asm volatile("" : "+v"(slot));
+        e = convert_entry<true>(T.glut[T.gidx[slot]].hot.primary[idx], false);
+    }
     if (__builtin_expect(e > 0x7FFFu, 0)) {
         const uint32_t first = e & 0xFFFu;
         if (__builtin_expect(first == JD_LUT_NOSUB, 0)) {
@@ -633,10 +669,18 @@ __device__ __forceinline__ int extend_top(uint32_t v, uint32_t size) {
 #ifndef JD_RSTEPS
 #define JD_RSTEPS 2
 #endif
-/* AC symbol steps per iteration of the light decodes, after the one DC step.  Odd: DC step + AC
- * steps pair up, a refill after each pair. */
-#ifndef JD_ASTEPS
-#define JD_ASTEPS 3
+/* AC symbol steps per iteration of the light decodes, after the one step that takes any symbol.  Odd: the
+ * steps pair up, a refill after each pair.  Two instantiations, picked per image by the plan
+ * (jd_image::long_units): streams of short data units -- a dozen symbols, most of them in groups since round
+ * 3 -- finish a unit in a few steps and waste the rest of a long iteration (1080p q85: 1 + 1 steps 3.47 ms,
+ * 1 + 3: 3.64, 1 + 5: 3.80 for the sync stage); streams of long units (quality 100: 50 symbols a unit, no
+ * groups) pay every iteration's fixed part, the refill and the descriptor reload (config 2: 1 + 3 steps
+ * 1.36 ms, 1 + 1: 1.73). */
+#ifndef JD_ASTEPS_SHORT
+#define JD_ASTEPS_SHORT 1
+#endif
+#ifndef JD_ASTEPS_LONG
+#define JD_ASTEPS_LONG 3
 #endif
 struct BitReader {
     const char *base;          /* the image's clean stream (uniform: a scalar base + 32-bit lane offsets; the plan keeps a
@@ -732,10 +776,12 @@ __device__ __forceinline__ constexpr uint32_t cp_mark(uint32_t c) { return (c + 
  * of DC differences seen per component.  COMPARE: stop early at a checkpoint that matches the
  * recorded decode (whose exit state is old_exit).
  */
-template <bool COMPARE>
+template <bool COMPARE, bool LONG_UNITS>   /* LONG_UNITS: jd_image::long_units -- the longer iteration, no symbol groups in the tables */
 __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables &T, uint32_t in, uint32_t valid,
                                                     uint32_t *__restrict__ cp_state, int4 *__restrict__ cp_val,
                                                     uint32_t old_exit) {
+    constexpr int ASTEPS = LONG_UNITS ? JD_ASTEPS_LONG : JD_ASTEPS_SHORT;
+    constexpr bool PAIRS = !LONG_UNITS;
     uint32_t p = in & 63u, k = (in >> 6) & 127u, b = JD_ST_UNIT(in);
     uint32_t fl = 0;             /* OR of the entries since the last checkpoint: LE_WIDE, LE_BAD */
     int n = 0, dc0 = 0, dc1 = 0, dc2 = 0;  /* units completed, DC difference sums since the last checkpoint */
@@ -757,7 +803,7 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
             {
                 const bool isdc = k == 0u;
                 const uint32_t top = R.top();
-                const uint32_t e = lookup_entry<true>(T, tb, isdc, top);
+                const uint32_t e = lookup_entry<true, PAIRS>(T, tb, isdc, top, k);
                 fl |= e;
                 const uint32_t tot = e & 31u;
                 int d = extend_at(top, tot, (e >> 8) & 15u);
@@ -769,13 +815,13 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
                 const bool end = k >= 64u;
                 k = end ? 0u : k; n += end ? 1 : 0; b = end ? tb.nb : b;
             }
-            /* JD_ASTEPS AC symbols of the lanes inside a unit; a lane whose unit ends waits for the
-             * DC step of the next iteration */
+            /* ASTEPS AC symbols (or groups of them) of the lanes inside a unit; a lane whose unit ends waits for
+             * the first step of the next iteration */
 #pragma unroll
-            for (int st = 0; st < JD_ASTEPS; ++st) {
+            for (int st = 0; st < ASTEPS; ++st) {
                 if (k != 0u && p < lim) {
                     const uint32_t top = R.top();
-                    const uint32_t e = lookup_entry<true>(T, tb, false, top);
+                    const uint32_t e = lookup_entry<true, PAIRS>(T, tb, false, top, k);
                     fl |= e;
                     const uint32_t tot = e & 31u;
                     p += tot;
@@ -836,6 +882,7 @@ __device__ __forceinline__ LightResult decode_light(BitReader R, const SegTables
                                    guess is paid by a third of the segments (C3 sync: 1024: 4.33, 1536: 4.21, 2048: 4.34,
                                    3072: 4.29, 4096: 4.48 ms; config 5 3.23 / 3.23 / 3.28 / 3.35 / 3.46) */
 #endif
+template <bool PAIRS>
 __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTables &T, uint32_t p0, uint32_t valid) {
     uint32_t p = p0, k = 0, b = 0;
     R.init(p);
@@ -845,7 +892,7 @@ __device__ __forceinline__ uint32_t decode_state_only(BitReader R, const SegTabl
         for (int st = 0; st < JD_RSTEPS; ++st) {
             if (st == 0 || p < valid) {
                 const bool isdc = k == 0;
-                const uint32_t e = lookup_entry<true>(T, tb, isdc, R.top());
+                const uint32_t e = lookup_entry<true, PAIRS>(T, tb, isdc, R.top(), k);
                 const uint32_t tot = e & 31u;
                 p += tot;
                 k = isdc ? 1u : k + ((e >> 5) & 127u);
@@ -877,7 +924,15 @@ __device__ __forceinline__ void stage_tables(jd_lut_hot *s_lut, BlkDesc *s_blk, 
 #pragma unroll 1
         for (uint32_t i = threadIdx.x; i < HOT32; i += blockDim.x) {
             const uint32_t v = src[i];
-            dst[slot * HOT32 + i] = convert_entry<LIGHT>(v & 0xFFFFu, is_dc) | (convert_entry<LIGHT>(v >> 16, is_dc) << 16);
+            uint32_t lo = convert_entry<LIGHT>(v & 0xFFFFu, is_dc), hi = convert_entry<LIGHT>(v >> 16, is_dc);
+            /* first level of an AC table: groups where they fit.  Not for streams of long units (quality 100):
+             * their short symbols sit at every k, the single-symbol path from global memory would be taken all
+             * the time, and their batches are a matter of one lane's latency (config 2: sync 1.36 -> 1.80 ms) */
+            if (LIGHT && !is_dc && !im.long_units && i < (1u << JD_LUT_BITS) / 2u) {
+                lo = pair_entry(lo, 2u * i, g.hot.primary);
+                hi = pair_entry(hi, 2u * i + 1u, g.hot.primary);
+            }
+            dst[slot * HOT32 + i] = lo | (hi << 16);
         }
     }
     if (threadIdx.x < JD_MAX_BPM) {
@@ -973,13 +1028,18 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_first(const jd_image *__res
             if (h == 0) {
                 const uint32_t pv = seg_info[gs - 1] & SEG_MASK; /* JD_SEG_BITS: only the last segment of an interval is short */
                 const uint32_t ov = span > 1u ? JD_OVERLAP_SPAN : JD_OVERLAP;
-                in = decode_state_only(make_reader(cimg, seg - 1, n_segs), T, pv > ov ? pv - ov : 0u, pv);
+                const uint32_t p0 = pv > ov ? pv - ov : 0u;
+                in = im.long_units ? decode_state_only<false>(make_reader(cimg, seg - 1, n_segs), T, p0, pv)
+                                   : decode_state_only<true>(make_reader(cimg, seg - 1, n_segs), T, p0, pv);
             } else {
                 in = prev_exit & ~JD_ST_BAD;
             }
         }
-        const LightResult r = decode_light<false>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
-                                                  cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
+        const LightResult r = im.long_units   /* wave-uniform: a scalar branch */
+            ? decode_light<false, true>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
+                                                  cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u)
+            : decode_light<false, false>(make_reader(cimg, seg, n_segs), T, in, si & SEG_MASK,
+                                                   cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), 0u);
         st_in[gs] = in;
         st_exit[gs] = r.exit_state;
         /* with the unit count: did the segment hold an AC coefficient of 8 or more magnitude bits
@@ -1054,9 +1114,12 @@ __global__ __launch_bounds__(JD_WG_SEGS) void k_huff_repair(const jd_image *__re
      * the list too and change its exit state while this lane reads it: either value is a
      * consistent start, and the next check lists this segment again if it was the old one. */
     const uint32_t in = st_exit[gs - 1] & ~JD_ST_BAD;
-    const LightResult r = decode_light<true>(make_reader(clean + im.clean_off, seg, im.n_segs), T, in, seg_info[gs] & SEG_MASK,
-                                             cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u),
-                                             st_exit[gs] & ~JD_ST_BAD);
+    const uint32_t old_exit = st_exit[gs] & ~JD_ST_BAD;
+    const LightResult r = im.long_units
+        ? decode_light<true, true>(make_reader(clean + im.clean_off, seg, im.n_segs), T, in, seg_info[gs] & SEG_MASK,
+                                             cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), old_exit)
+        : decode_light<true, false>(make_reader(clean + im.clean_off, seg, im.n_segs), T, in, seg_info[gs] & SEG_MASK,
+                                              cp_state + (size_t)gs * JD_CP, cp_val + (size_t)gs * (JD_CP + 1u), old_exit);
     st_in[gs] = in;
     st_exit[gs] = r.exit_state;
     cnt[gs] = make_int4(r.n, r.dc0, r.dc1, r.dc2);

@@ -116,6 +116,9 @@ JD_HD jd_sym jd_lut_lookup(const jd_lut_hot *h, const jd_lut *t, uint32_t v16) {
 #define JD_ST_NONE 0xFFFFFFFFu
 
 #define JD_NARROW_MIN_Q63 8u
+#ifndef JD_LONG_UNIT_BITS
+#define JD_LONG_UNIT_BITS 128u
+#endif
 typedef struct {
     uint64_t raw_off;      /* byte offset of the stuffed scan in the raw buffer */
     uint64_t clean_off;    /* byte offset of the clean stream (multiple of JD_SEG_BYTES) */
@@ -147,7 +150,8 @@ typedef struct {
     uint8_t  pre_wide;              /* 1: take the wide (int16, 128-byte unit) path whatever the light decodes see:
                                        a table whose last entry is below JD_NARROW_MIN_Q63 makes a last AC
                                        coefficient beyond the narrow unit's 4 bits likely enough */
-    uint8_t  pad_[1];
+    uint8_t  long_units;            /* 1: data units of many symbols (scan bits per unit >= JD_LONG_UNIT_BITS): the light
+                                       decodes take their longer iteration (JD_ASTEPS_LONG, jdgpu.hip) */
     uint32_t stride;                /* output pixels from one row to the next: width, or with JDGPU_OUT_PITCHED the
                                        next count that puts every row on a 256-byte boundary */
     uint32_t first_span;            /* consecutive segments a lane of k_huff_first takes in this image (1 .. JD_FIRST_SPAN_MAX, jd_plan_build) */

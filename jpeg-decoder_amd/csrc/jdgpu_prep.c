@@ -163,7 +163,7 @@ static void lut_index_free(lut_index *ix) { free(ix->slot); free(ix->spec); free
 
 /* What the Huffman kernels keep in LDS for a work-group: the lookup tables of the slots and the
  * per-unit descriptors.  Images with equal keys may share a work-group (one wave each). */
-typedef struct { uint16_t lut_idx[JD_LUT_SLOTS]; uint8_t nslots, bpm, comp[JD_MAX_BPM], dc[JD_MAX_BPM], ac[JD_MAX_BPM]; } table_key;
+typedef struct { uint16_t lut_idx[JD_LUT_SLOTS]; uint8_t nslots, bpm, long_units, comp[JD_MAX_BPM], dc[JD_MAX_BPM], ac[JD_MAX_BPM]; } table_key;
 
 /* ---- gathering the scans into one staging buffer ------------------------------------------------
  * 1.5 GB for a 4096 x 1080p batch: a single thread spends ~300 ms in first-touch page faults and
@@ -322,6 +322,13 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
         im->ri_blocks = ri ? ri * b : 0;
         im->n_intervals = ri ? (nmcu + ri - 1) / ri : 1;
         im->raw_len = (uint32_t)d->scan_len;
+        {
+            /* JDGPU_LONG_UNIT_BITS (experiments): threshold in scan bits per data unit */
+            const char *e = getenv("JDGPU_LONG_UNIT_BITS");
+            const uint64_t thr = e ? strtoull(e, NULL, 10) : JD_LONG_UNIT_BITS;
+            im->long_units = (uint64_t)d->scan_len * 8u >= thr * im->n_blocks;
+            keys[i].long_units = im->long_units;   /* the staged tables differ (symbol groups or not): no shared work-group */
+        }
         im->seg_cap = (uint32_t)((d->scan_len + JD_SEG_BYTES - 1) / JD_SEG_BYTES) + im->n_intervals;
         if ((uint64_t)((im->seg_cap + 63) / 64) * 64 * JD_SEG_BYTES >= 0xFFFFF000ull) {
             /* the bit readers address an image's clean stream with 32-bit byte offsets */
