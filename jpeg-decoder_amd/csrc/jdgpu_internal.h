@@ -180,6 +180,9 @@ typedef struct { uint32_t img, seg0; } jd_huff_wg;              /* one WAVE: 64 
                                          partly filled wave would cost it more than the overlap decodes saved
                                          (config 5, sync stage: 384: 3.19, 192: 3.33, 128: 3.50, 64: 3.53 ms) */
 #endif
+#ifndef JD_FIRST_SPAN3_MIN_SEGS
+#define JD_FIRST_SPAN3_MIN_SEGS 640u  /* ... and spans above 2 in images of at least this many segments, without restart intervals */
+#endif
 #define JD_NO_WAVE     0xFFFFFFFFu                             /* seg0 of a padding entry */
 #ifndef JD_WWG_WAVES_BIG
 #define JD_WWG_WAVES_BIG 8u                                    /* write kernel, batches whose images use ... */

@@ -426,7 +426,17 @@ int jd_plan_build(const jdgpu_image_desc *descs, size_t n, unsigned px_bytes, un
                 const char *fs = getenv("JDGPU_FIRST_SPAN");   /* tests and experiments: "3", or "3all" for images of any size */
                 if (fs && atoi(fs) >= 1 && atoi(fs) <= 16) { best = (uint32_t)atoi(fs); if (strstr(fs, "all")) min_segs = 0; }
             }
-            for (size_t i = 0; i < n; ++i) P->img[i].first_span = P->img[i].seg_cap >= min_segs ? best : 1u;
+            /* Round 3, after the light decodes learnt to take symbols in groups (the guess costs less now;
+             * sync stage, spans 1 / 2 / 3): C3 - / 3.69 / 3.59, config 4 (an interval of 22 segments per MCU
+             * row) 2.48 / 2.21 / 2.31, config 5 (mixed sizes) 2.94 / 2.99 / 3.11 ms.  So the longest span only in
+             * large images without restart intervals; forced spans (JDGPU_FIRST_SPAN) apply as given. */
+            const int forced = getenv("JDGPU_FIRST_SPAN") != NULL;
+            for (size_t i = 0; i < n; ++i) {
+                const jd_image *im = &P->img[i];
+                uint32_t sp = im->seg_cap >= min_segs ? best : 1u;
+                if (!forced && sp > 2u && (im->ri_blocks != 0 || im->seg_cap < JD_FIRST_SPAN3_MIN_SEGS)) sp = 2u;
+                P->img[i].first_span = sp;
+            }
         }
         /* The write kernel of a batch that leaves most of the chip idle (thumbnails, a single image)
          * is the latency of one lane's decode of a whole segment: there a segment is written by

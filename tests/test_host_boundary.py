@@ -605,7 +605,8 @@ def test_first_pass_work_list_and_span_rule(pkg):
 
     for copies, want in ((8, 1), (8192 // waves_big + 8, 2), (2 * 8192 // waves_big + 16, 3)):
         span, waves = plan([d3[i % 2] for i in range(copies)] + [d3[2]])
-        assert set(span[:-1]) == {want}, (copies, span[:4])
+        assert set(span[0:-1:2]) == {want}, (copies, span[:4])
+        assert set(span[1:-1:2]) == {min(want, 2)}, (copies, span[:4])   # restart intervals: a span of 2 at most (round 3)
         assert span[-1] == 1                      # the small image keeps one segment per lane
         assert waves >= copies * (waves_big // want) // 2
     for forced in ("1", "2", "5", "3all"):
