@@ -1240,7 +1240,9 @@ __constant__ uint8_t c_zz_cm[64];
  */
 #define WBUF_BYTES 128u
 #define JD_NARROW_UNIT 64u   /* bytes of a data unit in the coefficient buffer of a narrow image (a wide one: 128) */
-#define JD_WSTEPS JD_RSTEPS
+#ifndef JD_WSTEPS
+#define JD_WSTEPS JD_RSTEPS   /* symbol steps per iteration of the write kernel; the reader is refilled after every second one */
+#endif
 __device__ __forceinline__ uint32_t wbuf_key(uint32_t lane) {
     /* 16-byte chunks permuted by the lane number (XOR on the chunk index): both the lanes'
      * scattered stores and the 8-lanes-per-unit flush spread over the LDS banks, and the address of
@@ -1427,6 +1429,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_huff_write(const jd_image *__res
                 B += end ? 1 : 0; own = own || end; k = end ? 0u : k; b = end ? nb : b;
                 active = ok && (k != 0 || p < vend) && B < limit;
             }
+            if ((s & 1) && s + 1 < JD_WSTEPS) R.refill();   /* more than two steps: the window holds two symbols */
         }
         tb = s_blk[b]; /* once per iteration, all lanes: no divergent merge copies the descriptor around */
         R.refill(); /* all lanes, outside the divergent steps */
