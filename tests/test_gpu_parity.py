@@ -1196,6 +1196,47 @@ def test_batch_from_files_equals_batch_from_descriptors(pkg, dec):
     assert pkg.Batch.from_files([]).decode().n == 0
 
 
+def test_4096_mixed_images_from_files_from_pinned_memory_and_from_descriptors(pkg, dec, oracle):
+    """a 4096-image mixed batch (every fixture, every layout, restart intervals, two rejected
+    files) made three ways -- descriptors parsed on the host from ordinary memory (staging copy), whole files
+    in pinned memory with the headers parsed on the device (span upload), descriptors parsed on the host from
+    pinned memory (span upload) -- gives the same statuses and the same bytes for every image (compared on
+    the device), and the oracle's coefficients on a sample."""
+    import torch
+    mk = pkg.synth.make_jpeg
+    distinct = [golden_stream(n) for n in all_golden_names()]
+    distinct += [mk(333, 77, seed=3, quality=60, subsamp=1, restart_mcus=2), b"garbage", mk(17, 9, seed=4, quality=90, subsamp=0),
+                 mk(640, 480, seed=5, quality=85, subsamp=2), b"\xff\xd8\xff", mk(96, 72, seed=6, quality=80, subsamp=0x133),
+                 mk(1280, 720, seed=7, quality=85, subsamp=1), mk(200, 200, seed=8, quality=97, subsamp=0)]
+    files = [distinct[(7 * i) % len(distinct)] for i in range(4096)]
+    ref = pkg.Batch(pkg.parse_many(files, strict=False)).decode()
+    arena = pkg.Arena(files)
+    a = pkg.Batch.from_files(arena).decode()
+    b = pkg.Batch(pkg.parse_many(arena, strict=False)).decode()
+    assert a.create_ms()["stage"] == 0.0 and b.create_ms()["stage"] == 0.0 and ref.create_ms()["stage"] > 0.0
+    n_bad = 0
+    for i in range(4096):
+        st = ref.status(i)
+        assert a.status(i) == st and b.status(i) == st, i
+        if st & pkg.IMG_UNSUPPORTED:
+            n_bad += 1
+            continue
+        assert st == 0, (i, st)
+        t = ref.tensor(i)
+        assert torch.equal(a.tensor(i), t) and torch.equal(b.tensor(i), t), i
+    assert n_bad == sum(1 for f in files if f in (b"garbage", b"\xff\xd8\xff"))
+    first = {}
+    for i, f in enumerate(files):
+        first.setdefault(f, i)
+    for f, i in list(first.items()):
+        if ref.status(i) == 0:
+            _check_against_oracle(pkg, oracle, a, i, f)
+            q = a.qcoef(i)
+            j = max(k for k in range(4096) if files[k] is f)
+            assert np.array_equal(b.qcoef(j), q), (i, j)
+    arena.close()
+
+
 def _print_text(img, max_w, max_h, pw):
     """what image_print writes (src/image.c:13-31), stated in Python"""
     out = []
