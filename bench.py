@@ -289,9 +289,9 @@ def traffic_file():
 
 
 def with_traffic(r, workload, layout, pixels):
-    """HBM bytes per launch from the committed PMC passes: measured on the same workload shape at
-    256 images per launch, scaled per pixel to this launch; null for workloads the passes did not
-    cover.  `traffic_source` names the file and the commit of the kernels it was measured on, so a
+    """HBM bytes per launch from the committed PMC passes: measured on the same workload shape at the
+    benched launch size (4096 images per launch since round 3; the file says), scaled per pixel to this
+    launch; null for workloads the passes did not cover.  `traffic_source` names the file and the commit of the kernels it was measured on, so a
     figure older than the kernels is visible."""
     try:
         path = traffic_file()
@@ -306,8 +306,8 @@ def with_traffic(r, workload, layout, pixels):
                 r["achieved_measured"] = round(r["traffic"] / (r["avg_ms"] * 1e-3) / 1e9, 1)
                 r["frac_measured"] = round(r["achieved_measured"] / HBM_PEAK_GBS, 4)
             r["traffic_source"] = (f"{os.path.relpath(path, ROOT)} (kernels at commit {t.get('kernel_commit', 'unrecorded')}): "
-                                   "PMC FETCH_SIZE x2 + WRITE_SIZE (KiB), 256-image launch, scaled per pixel; "
-                                   "not a counter read of this run")
+                                   f"PMC FETCH_SIZE x2 + WRITE_SIZE (KiB) of a {t['images']}-image launch of this workload, "
+                                   "scaled per pixel to this launch; not a counter read of this run")
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return r
