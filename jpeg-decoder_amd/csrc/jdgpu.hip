@@ -2175,6 +2175,7 @@ struct jdgpu_batch {
                          gather runs on the batch's stream, in front of its first decode) */
     bool redo;       /* the current pass is a repeat: kernels skip the images whose word in the redo list is 0 */
     bool timed;
+    uint8_t *d_meta; /* small batches: the plan's arrays (d_img .. d_wwg, d_scan_src) are parts of this one buffer */
     float create_ms[JDGPU_NCREATE];   /* where the creation of this batch spent its time (jdgpu_batch_create_ms) */
 };
 
@@ -2186,6 +2187,8 @@ static int g_device = -1;
  * bound device (hipGetSymbolAddress in jdgpu_init); host code never uses the array's name for
  * anything else.  One call at a time uses it (g_scratch_mu). */
 #define JD_SCRATCH_BYTES (32u << 20)
+#define JD_CLEARED_WORDS (1u + 3u + JD_REPAIR_ROUNDS)   /* per image: d_status, d_wide, d_list_cnt (one block) */
+#define JD_META_PACK_MAX ((size_t)256 << 10)   /* plans up to this size go up as one buffer (jdgpu_batch_create) */
 static __device__ __align__(256) uint8_t scratch[JD_SCRATCH_BYTES];
 static uint8_t *g_scratch = nullptr;
 static std::mutex g_scratch_mu;
@@ -2314,6 +2317,38 @@ extern "C" void jdgpu_trim(void) {
     pool_trim_locked(0);
 }
 
+/* A batch's stream and events are recycled as well: creating and destroying a stream costs 67 + 62 us, a tenth
+ * of a single-image decode (rocprofv3 --hip-trace of bin/latency on birb.jpg). */
+struct StreamSet { hipStream_t stream; hipEvent_t ev[JDGPU_NSTAGES + 1]; };
+static std::mutex g_streams_mu;
+static std::vector<StreamSet> g_streams_free;
+static const size_t JD_STREAMS_KEPT = 16;
+static hipError_t stream_set_take(StreamSet *out) {
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        if (!g_streams_free.empty()) { *out = g_streams_free.back(); g_streams_free.pop_back(); return hipSuccess; }
+    }
+    StreamSet s{};
+    hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    for (auto &ev : s.ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        for (auto &ev : s.ev) if (ev) hipEventDestroy(ev);
+        if (s.stream) hipStreamDestroy(s.stream);
+        return e;
+    }
+    *out = s;
+    return hipSuccess;
+}
+/* the caller has synchronised the stream */
+static void stream_set_give(const StreamSet &s) {
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        if (g_streams_free.size() < JD_STREAMS_KEPT) { g_streams_free.push_back(s); return; }
+    }
+    for (auto &ev : s.ev) hipEventDestroy(ev);
+    hipStreamDestroy(s.stream);
+}
+
 template <class T>
 static int dalloc(T **p, size_t count) {
     return pool_alloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
@@ -2336,13 +2371,21 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     /* the buffers go back to the cache and may be handed out at once: nothing of this batch may
      * still be running (hipFree used to wait for the whole device here) */
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->d_meta) { /* these are parts of d_meta */
+        b->d_img = nullptr; b->d_luts = nullptr; b->d_hwg = b->d_rpl = b->d_fwg = b->d_wwg = nullptr;
+        b->d_pwg = nullptr; b->d_rwg = nullptr; b->d_scan_src = nullptr;
+    }
     void *bufs[] = {b->d_raw, b->d_clean, b->d_pix, b->d_img, b->d_luts, b->d_seg_info, b->d_st_in, b->d_st_exit, b->d_list,
-                    b->d_list_cnt, b->d_status, b->d_wide, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
+                    b->d_status, b->d_cnt, b->d_cp_state, b->d_cp_val, b->d_start_dc, b->d_start_blk, b->d_coef,
                     b->d_hwg, b->d_pwg, b->d_rwg, b->d_wwg, b->d_rpl, b->d_chunk_cnt, b->d_chunk_base, b->d_ivl_u, b->d_ivl_seg,
-                    b->d_lane_masks, b->d_files, b->d_scan_src, b->d_fwg};
+                    b->d_lane_masks, b->d_files, b->d_scan_src, b->d_fwg, b->d_meta};
     for (void *p : bufs) pool_free(p);
-    for (auto &e : b->ev) if (e) hipEventDestroy(e);
-    if (b->stream) hipStreamDestroy(b->stream);
+    if (b->stream) {
+        StreamSet s;
+        s.stream = b->stream;
+        for (int k = 0; k <= JDGPU_NSTAGES; ++k) s.ev[k] = b->ev[k];
+        stream_set_give(s);
+    }
     jd_plan_free(&b->plan);
     delete b;
 }
@@ -2450,7 +2493,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -2468,13 +2511,15 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->status.assign(n, 0);
     for (size_t i = 0; i < n; ++i) if (!P.img[i].ncomp) b->status[i] = JDGPU_IMG_UNSUPPORTED;
 
-    HIPTRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    for (auto &e : b->ev) HIPTRY(hipEventCreate(&e));
+    {
+        StreamSet s;
+        HIPTRY(stream_set_take(&s));
+        b->stream = s.stream;
+        for (int k = 0; k <= JDGPU_NSTAGES; ++k) b->ev[k] = s.ev[k];
+    }
     TRY(dalloc(&b->d_raw, P.raw_bytes));
     TRY(dalloc(&b->d_clean, P.clean_bytes));
     TRY(dalloc(&b->d_pix, (size_t)P.pix_bytes + 256));
-    TRY(dalloc(&b->d_img, n));
-    TRY(dalloc(&b->d_luts, (size_t)P.n_luts));
     TRY(dalloc(&b->d_seg_info, (size_t)P.n_segs_cap + 1));
     TRY(dalloc(&b->d_st_in, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_st_exit, (size_t)P.n_segs_cap));
@@ -2484,17 +2529,13 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     TRY(dalloc(&b->d_start_dc, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_start_blk, (size_t)P.n_segs_cap));
     TRY(dalloc(&b->d_list, (size_t)P.n_segs_cap));
-    TRY(dalloc(&b->d_list_cnt, (size_t)JD_REPAIR_ROUNDS * (n ? n : 1)));
-    TRY(dalloc(&b->d_status, n));
-    TRY(dalloc(&b->d_wide, 3 * (n ? n : 1))); /* second part: where a test sends the flags to lose them; third: the
-                                                 images a later pass has to do again (redo_of) */
+    /* one block, so that a decode clears it with one fill: the status words [n], the wide flags [3n] (second
+     * part: where a test sends the flags to lose them; third: the images a later pass has to do again, redo_of)
+     * and the repair lists' counts [JD_REPAIR_ROUNDS][n] */
+    TRY(dalloc(&b->d_status, (size_t)JD_CLEARED_WORDS * (n ? n : 1)));
+    b->d_wide = b->d_status + (n ? n : 1);
+    b->d_list_cnt = b->d_wide + 3 * (n ? n : 1);
     TRY(dalloc(&b->d_coef, (size_t)P.total_blocks * 64));
-    TRY(dalloc(&b->d_hwg, (size_t)P.n_hwg * JD_WG_WAVES));
-    TRY(dalloc(&b->d_rpl, (size_t)P.n_hwg * JD_WG_WAVES));
-    TRY(dalloc(&b->d_fwg, (size_t)P.n_fwg * JD_WG_WAVES));
-    TRY(dalloc(&b->d_pwg, (size_t)P.n_pwg));
-    TRY(dalloc(&b->d_rwg, (size_t)P.n_rwg));
-    TRY(dalloc(&b->d_wwg, (size_t)P.n_wwg * P.wwg_waves));
     TRY(dalloc(&b->d_chunk_cnt, (size_t)P.n_rwg));
     TRY(dalloc(&b->d_lane_masks, (size_t)P.n_rwg * 256u));
     TRY(dalloc(&b->d_chunk_base, (size_t)P.n_rwg));
@@ -2542,19 +2583,44 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
             lap(JDGPU_CREATE_UPLOAD, "scan upload");
         }
     }
-    HIPTRY(hipMemcpyAsync(b->d_img, P.img, n * sizeof(jd_image), hipMemcpyHostToDevice, b->stream));
-    if (P.n_luts) HIPTRY(hipMemcpyAsync(b->d_luts, P.luts, (size_t)P.n_luts * sizeof(jd_lut), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_hwg, P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_rpl, P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_fwg, P.fwg, (size_t)P.n_fwg * JD_WG_WAVES * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_pwg, P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_rwg, P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg), hipMemcpyHostToDevice, b->stream));
-    HIPTRY(hipMemcpyAsync(b->d_wwg, P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg), hipMemcpyHostToDevice, b->stream));
+    /* the plan's arrays.  A small batch (a single image above all) takes them up as ONE buffer and one copy:
+     * eight allocations and nine copies of a few hundred bytes each cost ~10 us apiece, 0.1 ms of a
+     * single-image decode's 1.2. */
+    struct Part { void **dev; const void *host; size_t bytes; };
+    const Part parts[] = {
+        {reinterpret_cast<void **>(&b->d_img), P.img, n * sizeof(jd_image)},
+        {reinterpret_cast<void **>(&b->d_luts), P.luts, (size_t)P.n_luts * sizeof(jd_lut)},
+        {reinterpret_cast<void **>(&b->d_hwg), P.hwg, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg)},
+        {reinterpret_cast<void **>(&b->d_rpl), P.rpl, (size_t)P.n_hwg * JD_WG_WAVES * sizeof(jd_huff_wg)},
+        {reinterpret_cast<void **>(&b->d_fwg), P.fwg, (size_t)P.n_fwg * JD_WG_WAVES * sizeof(jd_huff_wg)},
+        {reinterpret_cast<void **>(&b->d_pwg), P.pwg, (size_t)P.n_pwg * sizeof(jd_pix_wg)},
+        {reinterpret_cast<void **>(&b->d_rwg), P.rwg, (size_t)P.n_rwg * sizeof(jd_raw_wg)},
+        {reinterpret_cast<void **>(&b->d_wwg), P.wwg, (size_t)P.n_wwg * P.wwg_waves * sizeof(jd_huff_wg)},
+        {reinterpret_cast<void **>(&b->d_scan_src), src.data(), on_device ? (n ? n : 1) * sizeof(uint64_t) : 0},
+    };
+    size_t meta_bytes = 0;
+    for (const Part &pt : parts) meta_bytes += (pt.bytes + 255) & ~(size_t)255;
+    std::vector<uint8_t> meta;   /* read by the copy below: lives until this call has waited for the stream */
+    if (meta_bytes <= JD_META_PACK_MAX) {
+        TRY(pool_alloc(reinterpret_cast<void **>(&b->d_meta), meta_bytes + 256));
+        meta.assign(meta_bytes + 256, 0);
+        size_t at = 0;
+        for (const Part &pt : parts) {
+            *pt.dev = b->d_meta + at;   /* an empty part points at the next one's start and is never read */
+            if (pt.bytes) memcpy(meta.data() + at, pt.host, pt.bytes);
+            at += (pt.bytes + 255) & ~(size_t)255;
+        }
+        HIPTRY(hipMemcpyAsync(b->d_meta, meta.data(), meta.size(), hipMemcpyHostToDevice, b->stream));
+    } else {
+        for (const Part &pt : parts) {
+            if (!pt.bytes && pt.dev == reinterpret_cast<void **>(&b->d_scan_src)) continue;
+            TRY(pool_alloc(pt.dev, pt.bytes ? pt.bytes : 1));
+            if (pt.bytes) HIPTRY(hipMemcpyAsync(*pt.dev, pt.host, pt.bytes, hipMemcpyHostToDevice, b->stream));
+        }
+    }
     if (on_device) {
         /* copied on the device into the raw buffer the unstuff stage reads (16-byte aligned starts, zeros after
          * each scan), on the batch's own stream */
-        TRY(dalloc(&b->d_scan_src, n));
-        HIPTRY(hipMemcpyAsync(b->d_scan_src, src.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice, b->stream));
         HIPTRY(hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream));
         if (P.n_rwg) {
             hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, b->d_scan_src, b->d_raw);
@@ -2572,7 +2638,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
             if (!P.img[i].ncomp)
                 HIPTRY(hipMemsetAsync(b->d_pix + P.img[i].pix_off, 0, (size_t)P.img[i].stride * P.img[i].height * P.px_bytes, b->stream));
     }
-    HIPTRY(hipMemsetAsync(b->d_status, 0, (n ? n : 1) * 4, b->stream));
+    HIPTRY(hipMemsetAsync(b->d_status, 0, (size_t)JD_CLEARED_WORDS * (n ? n : 1) * 4, b->stream));
     /* Everything above reads host memory of this call (the plan's arrays, the caller's scans) or, with
      * JDGPU_SCAN_ON_DEVICE, device memory the caller may release when this returns: wait for it.  The
      * exception: files the batch owns (jdgpu_batch_create_from_files adopted them) and plan arrays, which live
@@ -2679,7 +2745,7 @@ static int enqueue_huffman(jdgpu_batch *b, bool first_pass) {
         hipLaunchKernelGGL(k_huff_first, dim3(P.n_fwg), block, 0, st, b->d_img, b->d_luts, b->d_clean, b->d_seg_info, b->d_fwg,
                            b->d_st_in, b->d_st_exit, b->d_cnt, b->d_cp_state, b->d_cp_val);
     /* chain check + repair; on a later pass (k_huff_write still found a break) the same again */
-    HIPCHK(hipMemsetAsync(b->d_list_cnt, 0, (size_t)JD_REPAIR_ROUNDS * P.n * 4, st));
+    if (!first_pass) HIPCHK(hipMemsetAsync(b->d_list_cnt, 0, (size_t)JD_REPAIR_ROUNDS * P.n * 4, st)); /* jdgpu_batch_decode has */
     /* JDGPU_TEST_REPAIR_ROUNDS (tests): fewer built-in rounds in the first pass, so that chains are still
      * broken when k_huff_write checks them and the second-pass machinery of jdgpu_batch_sync has work */
     uint32_t rounds = JD_REPAIR_ROUNDS;
@@ -2703,8 +2769,8 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     b->retries = 0;
     b->redo = false;
     hipStream_t st = b->stream;
-    HIPCHK(hipMemsetAsync(b->d_status, 0, P.n * 4, st));
-    HIPCHK(hipMemsetAsync(b->d_wide, 0, P.n * 4, st)); /* set by the light decodes, kept over repair passes */
+    /* status, wide flags (set by the light decodes, kept over repair passes) and repair counts */
+    HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)JD_CLEARED_WORDS * P.n * 4, st));
     if (prof) HIPCHK(hipEventRecord(b->ev[0], st));
     if (P.n_rwg) {
         HIPCHK(hipMemsetAsync(b->d_ivl_u, 0xFF, (size_t)P.n_u * 4, st));
