@@ -2176,6 +2176,10 @@ struct jdgpu_batch {
     bool redo;       /* the current pass is a repeat: kernels skip the images whose word in the redo list is 0 */
     bool timed;
     uint8_t *d_meta; /* small batches: the plan's arrays (d_img .. d_wwg, d_scan_src) are parts of this one buffer */
+    std::vector<uint8_t> meta_host;   /* ... and what their upload reads (it may still run when the creation returns) */
+    uint32_t *h_status;   /* pinned, JD_HSTATUS_WORDS words, recycled with the stream: where a decode's status words
+                             land without a copy call of their own (batches of at most that many images) */
+    bool status_copied;   /* the decode in flight ends with that copy */
     float create_ms[JDGPU_NCREATE];   /* where the creation of this batch spent its time (jdgpu_batch_create_ms) */
 };
 
@@ -2319,7 +2323,8 @@ extern "C" void jdgpu_trim(void) {
 
 /* A batch's stream and events are recycled as well: creating and destroying a stream costs 67 + 62 us, a tenth
  * of a single-image decode (rocprofv3 --hip-trace of bin/latency on birb.jpg). */
-struct StreamSet { hipStream_t stream; hipEvent_t ev[JDGPU_NSTAGES + 1]; };
+#define JD_HSTATUS_WORDS 4096u
+struct StreamSet { hipStream_t stream; hipEvent_t ev[JDGPU_NSTAGES + 1]; uint32_t *h_status; };
 static std::mutex g_streams_mu;
 static std::vector<StreamSet> g_streams_free;
 static const size_t JD_STREAMS_KEPT = 16;
@@ -2331,6 +2336,7 @@ static hipError_t stream_set_take(StreamSet *out) {
     StreamSet s{};
     hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     for (auto &ev : s.ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_status), JD_HSTATUS_WORDS * 4u, hipHostMallocDefault);
     if (e != hipSuccess) {
         for (auto &ev : s.ev) if (ev) hipEventDestroy(ev);
         if (s.stream) hipStreamDestroy(s.stream);
@@ -2347,6 +2353,7 @@ static void stream_set_give(const StreamSet &s) {
     }
     for (auto &ev : s.ev) hipEventDestroy(ev);
     hipStreamDestroy(s.stream);
+    hipHostFree(s.h_status);
 }
 
 template <class T>
@@ -2384,6 +2391,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
         StreamSet s;
         s.stream = b->stream;
         for (int k = 0; k <= JDGPU_NSTAGES; ++k) s.ev[k] = b->ev[k];
+        s.h_status = b->h_status;
         stream_set_give(s);
     }
     jd_plan_free(&b->plan);
@@ -2493,7 +2501,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr; b->h_status = nullptr; b->status_copied = false;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -2516,6 +2524,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
         HIPTRY(stream_set_take(&s));
         b->stream = s.stream;
         for (int k = 0; k <= JDGPU_NSTAGES; ++k) b->ev[k] = s.ev[k];
+        b->h_status = s.h_status;
     }
     TRY(dalloc(&b->d_raw, P.raw_bytes));
     TRY(dalloc(&b->d_clean, P.clean_bytes));
@@ -2600,8 +2609,9 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     };
     size_t meta_bytes = 0;
     for (const Part &pt : parts) meta_bytes += (pt.bytes + 255) & ~(size_t)255;
-    std::vector<uint8_t> meta;   /* read by the copy below: lives until this call has waited for the stream */
-    if (meta_bytes <= JD_META_PACK_MAX) {
+    std::vector<uint8_t> &meta = b->meta_host;   /* read by the copy below: lives as long as the batch */
+    const bool packed = meta_bytes <= JD_META_PACK_MAX;
+    if (packed) {
         TRY(pool_alloc(reinterpret_cast<void **>(&b->d_meta), meta_bytes + 256));
         meta.assign(meta_bytes + 256, 0);
         size_t at = 0;
@@ -2644,7 +2654,9 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
      * exception: files the batch owns (jdgpu_batch_create_from_files adopted them) and plan arrays, which live
      * as long as the batch -- but the pageable plan arrays are staged by the runtime at enqueue time only when
      * small; so wait in every case, it is the upload's duration and nothing else. */
-    HIPTRY(hipStreamSynchronize(b->stream));
+    /* ... except where nothing of that kind is left: a packed plan (its host copy belongs to the batch) whose
+     * scans the library uploaded itself.  A single image's creation then ends without a wait. */
+    if (!packed || (flags & JDGPU_SCAN_ON_DEVICE)) HIPTRY(hipStreamSynchronize(b->stream));
     lap(JDGPU_CREATE_UPLOAD, "uploads, device gather");
     if (trace) fprintf(stderr, "[jdgpu]   (%.2f GB of scans, %u distinct Huffman tables)\n", P.raw_bytes / 1e9, P.n_luts);
     /* the host copies of the bulky arrays are not needed any more */
@@ -2796,6 +2808,8 @@ extern "C" int jdgpu_batch_decode(jdgpu_batch *b) {
     }
     if (prof) HIPCHK(hipEventRecord(b->ev[5], st));
     HIPCHK(hipGetLastError());
+    b->status_copied = b->h_status && P.n <= JD_HSTATUS_WORDS;
+    if (b->status_copied) HIPCHK(hipMemcpyAsync(b->h_status, b->d_status, P.n * 4, hipMemcpyDeviceToHost, st));
     b->timed = prof;
     return JDGPU_OK;
 }
@@ -2807,7 +2821,9 @@ extern "C" int jdgpu_batch_sync(jdgpu_batch *b) {
     if (P.n == 0) return JDGPU_OK;
     std::vector<uint32_t> st(P.n);
     for (int attempt = 0;; ++attempt) {
-        HIPCHK(hipMemcpy(st.data(), b->d_status, P.n * 4, hipMemcpyDeviceToHost));
+        if (attempt == 0 && b->status_copied) memcpy(st.data(), b->h_status, P.n * 4);   /* came with the decode */
+        else HIPCHK(hipMemcpy(st.data(), b->d_status, P.n * 4, hipMemcpyDeviceToHost));
+        b->status_copied = false;
         bool unsynced = false;
         for (size_t i = 0; i < P.n; ++i) unsynced |= (st[i] & JDGPU_IMG_UNSYNCED) != 0;
         if (!unsynced) break;
