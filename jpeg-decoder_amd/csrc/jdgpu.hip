@@ -2180,6 +2180,7 @@ struct jdgpu_batch {
     uint32_t *h_status;   /* pinned, JD_HSTATUS_WORDS words, recycled with the stream: where a decode's status words
                              land without a copy call of their own (batches of at most that many images) */
     bool status_copied;   /* the decode in flight ends with that copy */
+    hipEvent_t ev_created; /* the creation's GPU work (on g_hi) has ended: the batch's stream waits for it */
     float create_ms[JDGPU_NCREATE];   /* where the creation of this batch spent its time (jdgpu_batch_create_ms) */
 };
 
@@ -2196,6 +2197,13 @@ static int g_device = -1;
 static __device__ __align__(256) uint8_t scratch[JD_SCRATCH_BYTES];
 static uint8_t *g_scratch = nullptr;
 static std::mutex g_scratch_mu;
+
+/* The GPU work of a batch's CREATION (header parse, small uploads, fills, the scan gather: a millisecond of
+ * kernels) runs on one stream of the highest priority.  On a batch's own stream, or on the null stream, such
+ * a kernel waited for the work-groups of whatever batch was decoding at the time -- 8 to 19 ms instead of
+ * 0.1 for the header parse under a running decode (rocprofv3 / JDGPU_TRACE) -- and a loader's creations,
+ * which have to keep the PCIe link busy, lost that time.  Null when the device offers no priorities. */
+static hipStream_t g_hi = nullptr;
 
 extern "C" const char *jdgpu_last_error(void) { return g_err; }
 
@@ -2228,6 +2236,10 @@ extern "C" int jdgpu_init(int device) {
         void *sp = nullptr;
         HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
         g_scratch = static_cast<uint8_t *>(sp);
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+            if (hipStreamCreateWithPriority(&g_hi, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); g_hi = nullptr; }
+        }
         g_device = device;
     }
     return JDGPU_OK;
@@ -2324,7 +2336,7 @@ extern "C" void jdgpu_trim(void) {
 /* A batch's stream and events are recycled as well: creating and destroying a stream costs 67 + 62 us, a tenth
  * of a single-image decode (rocprofv3 --hip-trace of bin/latency on birb.jpg). */
 #define JD_HSTATUS_WORDS 4096u
-struct StreamSet { hipStream_t stream; hipEvent_t ev[JDGPU_NSTAGES + 1]; uint32_t *h_status; };
+struct StreamSet { hipStream_t stream; hipEvent_t ev[JDGPU_NSTAGES + 1]; hipEvent_t created; uint32_t *h_status; };
 static std::mutex g_streams_mu;
 static std::vector<StreamSet> g_streams_free;
 static const size_t JD_STREAMS_KEPT = 16;
@@ -2336,8 +2348,10 @@ static hipError_t stream_set_take(StreamSet *out) {
     StreamSet s{};
     hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     for (auto &ev : s.ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.created, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_status), JD_HSTATUS_WORDS * 4u, hipHostMallocDefault);
     if (e != hipSuccess) {
+        if (s.created) hipEventDestroy(s.created);
         for (auto &ev : s.ev) if (ev) hipEventDestroy(ev);
         if (s.stream) hipStreamDestroy(s.stream);
         return e;
@@ -2352,6 +2366,7 @@ static void stream_set_give(const StreamSet &s) {
         if (g_streams_free.size() < JD_STREAMS_KEPT) { g_streams_free.push_back(s); return; }
     }
     for (auto &ev : s.ev) hipEventDestroy(ev);
+    hipEventDestroy(s.created);
     hipStreamDestroy(s.stream);
     hipHostFree(s.h_status);
 }
@@ -2392,6 +2407,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
         s.stream = b->stream;
         for (int k = 0; k <= JDGPU_NSTAGES; ++k) s.ev[k] = b->ev[k];
         s.h_status = b->h_status;
+        s.created = b->ev_created;
         stream_set_give(s);
     }
     jd_plan_free(&b->plan);
@@ -2501,7 +2517,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr; b->h_status = nullptr; b->status_copied = false;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr; b->h_status = nullptr; b->status_copied = false; b->ev_created = nullptr;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -2525,6 +2541,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
         b->stream = s.stream;
         for (int k = 0; k <= JDGPU_NSTAGES; ++k) b->ev[k] = s.ev[k];
         b->h_status = s.h_status;
+        b->ev_created = s.created;
     }
     TRY(dalloc(&b->d_raw, P.raw_bytes));
     TRY(dalloc(&b->d_clean, P.clean_bytes));
@@ -2559,6 +2576,10 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
      * the library's pinned staging buffer, one upload. */
     std::vector<uint64_t> src;
     bool on_device = (flags & JDGPU_SCAN_ON_DEVICE) != 0;
+    /* held from the span upload to the submission of the plan's arrays: submitted after ANOTHER creation's bulk
+     * upload, those few MB wait for all of it (28 ms instead of 2), and two creating threads that meet once that
+     * way stay in step from then on, the link idle while both plan */
+    std::unique_lock<std::mutex> up(g_upload_mu, std::defer_lock);
     if (on_device) {
         src.resize(n ? n : 1);
         for (size_t i = 0; i < n; ++i) src[i] = (uint64_t)(uintptr_t)descs[i].scan;
@@ -2573,10 +2594,8 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
             uint8_t *d_span = nullptr;
             TRY(pool_alloc(reinterpret_cast<void **>(&d_span), (size_t)(hi - lo) + 16));
             b->d_files = d_span;   /* released with the batch */
-            {
-                std::lock_guard<std::mutex> up(g_upload_mu);
-                HIPTRY(hipMemcpy(d_span, lo, (size_t)(hi - lo), hipMemcpyHostToDevice));
-            }
+            up.lock();   /* released below, or by any return */
+            HIPTRY(hipMemcpy(d_span, lo, (size_t)(hi - lo), hipMemcpyHostToDevice));
             lap(JDGPU_CREATE_UPLOAD, "span upload");
             src.resize(n ? n : 1);
             for (size_t i = 0; i < n; ++i) src[i] = P.img[i].ncomp ? (uint64_t)(uintptr_t)(d_span + (descs[i].scan - lo)) : 0;
@@ -2611,6 +2630,9 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     for (const Part &pt : parts) meta_bytes += (pt.bytes + 255) & ~(size_t)255;
     std::vector<uint8_t> &meta = b->meta_host;   /* read by the copy below: lives as long as the batch */
     const bool packed = meta_bytes <= JD_META_PACK_MAX;
+    /* where the creation's GPU work goes: a large batch's on the high-priority stream (see g_hi), a small one's
+     * on its own stream (no one to wait for, and no event between two streams in a single image's latency) */
+    const hipStream_t cs = (g_hi && !packed) ? g_hi : b->stream;
     if (packed) {
         TRY(pool_alloc(reinterpret_cast<void **>(&b->d_meta), meta_bytes + 256));
         meta.assign(meta_bytes + 256, 0);
@@ -2620,20 +2642,21 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
             if (pt.bytes) memcpy(meta.data() + at, pt.host, pt.bytes);
             at += (pt.bytes + 255) & ~(size_t)255;
         }
-        HIPTRY(hipMemcpyAsync(b->d_meta, meta.data(), meta.size(), hipMemcpyHostToDevice, b->stream));
+        HIPTRY(hipMemcpyAsync(b->d_meta, meta.data(), meta.size(), hipMemcpyHostToDevice, cs));
     } else {
         for (const Part &pt : parts) {
             if (!pt.bytes && pt.dev == reinterpret_cast<void **>(&b->d_scan_src)) continue;
             TRY(pool_alloc(pt.dev, pt.bytes ? pt.bytes : 1));
-            if (pt.bytes) HIPTRY(hipMemcpyAsync(*pt.dev, pt.host, pt.bytes, hipMemcpyHostToDevice, b->stream));
+            if (pt.bytes) HIPTRY(hipMemcpyAsync(*pt.dev, pt.host, pt.bytes, hipMemcpyHostToDevice, cs));
         }
     }
+    if (up.owns_lock()) up.unlock();
     if (on_device) {
         /* copied on the device into the raw buffer the unstuff stage reads (16-byte aligned starts, zeros after
          * each scan), on the batch's own stream */
-        HIPTRY(hipMemsetAsync(b->d_raw, 0, P.raw_bytes, b->stream));
+        HIPTRY(hipMemsetAsync(b->d_raw, 0, P.raw_bytes, cs));
         if (P.n_rwg) {
-            hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, b->stream, b->d_img, b->d_rwg, b->d_scan_src, b->d_raw);
+            hipLaunchKernelGGL(k_gather_scans, dim3(P.n_rwg), dim3(256), 0, cs, b->d_img, b->d_rwg, b->d_scan_src, b->d_raw);
             HIPTRY(hipGetLastError());
         }
     }
@@ -2642,13 +2665,13 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
      * image is zeroed when its status is known (jdgpu_batch_sync); clearing 25 GB per batch here cost
      * 4.3 ms of the GPU, a fifth of a decode. */
     if (flags & JDGPU_OUT_PITCHED) {
-        HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, b->stream));
+        HIPTRY(hipMemsetAsync(b->d_pix, 0, (size_t)P.pix_bytes + 256, cs));
     } else {
         for (size_t i = 0; i < n; ++i)
             if (!P.img[i].ncomp)
-                HIPTRY(hipMemsetAsync(b->d_pix + P.img[i].pix_off, 0, (size_t)P.img[i].stride * P.img[i].height * P.px_bytes, b->stream));
+                HIPTRY(hipMemsetAsync(b->d_pix + P.img[i].pix_off, 0, (size_t)P.img[i].stride * P.img[i].height * P.px_bytes, cs));
     }
-    HIPTRY(hipMemsetAsync(b->d_status, 0, (size_t)JD_CLEARED_WORDS * (n ? n : 1) * 4, b->stream));
+    HIPTRY(hipMemsetAsync(b->d_status, 0, (size_t)JD_CLEARED_WORDS * (n ? n : 1) * 4, cs));
     /* Everything above reads host memory of this call (the plan's arrays, the caller's scans) or, with
      * JDGPU_SCAN_ON_DEVICE, device memory the caller may release when this returns: wait for it.  The
      * exception: files the batch owns (jdgpu_batch_create_from_files adopted them) and plan arrays, which live
@@ -2656,7 +2679,13 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
      * small; so wait in every case, it is the upload's duration and nothing else. */
     /* ... except where nothing of that kind is left: a packed plan (its host copy belongs to the batch) whose
      * scans the library uploaded itself.  A single image's creation then ends without a wait. */
-    if (!packed || (flags & JDGPU_SCAN_ON_DEVICE)) HIPTRY(hipStreamSynchronize(b->stream));
+    if (cs != b->stream) {   /* the batch's stream starts behind the creation's work; the host waits for that work alone */
+        HIPTRY(hipEventRecord(b->ev_created, cs));
+        HIPTRY(hipStreamWaitEvent(b->stream, b->ev_created, 0));
+        HIPTRY(hipEventSynchronize(b->ev_created));
+    } else if (!packed || (flags & JDGPU_SCAN_ON_DEVICE)) {
+        HIPTRY(hipStreamSynchronize(b->stream));
+    }
     lap(JDGPU_CREATE_UPLOAD, "uploads, device gather");
     if (trace) fprintf(stderr, "[jdgpu]   (%.2f GB of scans, %u distinct Huffman tables)\n", P.raw_bytes / 1e9, P.n_luts);
     /* the host copies of the bulky arrays are not needed any more */
