@@ -2181,6 +2181,7 @@ struct jdgpu_batch {
                              land without a copy call of their own (batches of at most that many images) */
     bool status_copied;   /* the decode in flight ends with that copy */
     hipEvent_t ev_created; /* the creation's GPU work (on g_hi) has ended: the batch's stream waits for it */
+    bool hi_pending;       /* work of this batch may still run on g_hi (a creation that failed half way) */
     float create_ms[JDGPU_NCREATE];   /* where the creation of this batch spent its time (jdgpu_batch_create_ms) */
 };
 
@@ -2393,6 +2394,7 @@ extern "C" void jdgpu_batch_destroy(jdgpu_batch *b) {
     /* the buffers go back to the cache and may be handed out at once: nothing of this batch may
      * still be running (hipFree used to wait for the whole device here) */
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->hi_pending && g_hi) hipStreamSynchronize(g_hi);
     if (b->d_meta) { /* these are parts of d_meta */
         b->d_img = nullptr; b->d_luts = nullptr; b->d_hwg = b->d_rpl = b->d_fwg = b->d_wwg = nullptr;
         b->d_pwg = nullptr; b->d_rwg = nullptr; b->d_scan_src = nullptr;
@@ -2517,7 +2519,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     b->d_seg_info = b->d_st_in = b->d_st_exit = b->d_list = b->d_list_cnt = b->d_status = b->d_wide = nullptr;
     b->d_cp_state = nullptr; b->d_cp_val = nullptr;
     b->d_cnt = b->d_start_dc = nullptr; b->d_start_blk = nullptr; b->d_coef = nullptr; b->d_hwg = nullptr; b->d_pwg = nullptr;
-    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr; b->h_status = nullptr; b->status_copied = false; b->ev_created = nullptr;
+    b->d_rwg = nullptr; b->d_wwg = nullptr; b->d_rpl = nullptr; b->d_fwg = nullptr; b->d_chunk_cnt = b->d_chunk_base = nullptr; b->d_ivl_u = b->d_ivl_seg = nullptr; b->d_lane_masks = nullptr; b->any_rst = false; b->d_meta = nullptr; b->h_status = nullptr; b->status_copied = false; b->ev_created = nullptr; b->hi_pending = false;
     for (auto &e : b->ev) e = nullptr;
     const bool trace = getenv("JDGPU_TRACE") != nullptr;   /* development aid: where batch creation spends its time */
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -2633,6 +2635,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
     /* where the creation's GPU work goes: a large batch's on the high-priority stream (see g_hi), a small one's
      * on its own stream (no one to wait for, and no event between two streams in a single image's latency) */
     const hipStream_t cs = (g_hi && !packed) ? g_hi : b->stream;
+    b->hi_pending = cs != b->stream;
     if (packed) {
         TRY(pool_alloc(reinterpret_cast<void **>(&b->d_meta), meta_bytes + 256));
         meta.assign(meta_bytes + 256, 0);
@@ -2683,6 +2686,7 @@ extern "C" int jdgpu_batch_create(const jdgpu_image_desc *descs, size_t n, unsig
         HIPTRY(hipEventRecord(b->ev_created, cs));
         HIPTRY(hipStreamWaitEvent(b->stream, b->ev_created, 0));
         HIPTRY(hipEventSynchronize(b->ev_created));
+        b->hi_pending = false;
     } else if (!packed || (flags & JDGPU_SCAN_ON_DEVICE)) {
         HIPTRY(hipStreamSynchronize(b->stream));
     }
